@@ -1,0 +1,188 @@
+"""Benchmark of the ViLBERT two-stream hot path on MI355X (contract: see the task brief).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fwd|train] [--batch B]
+
+One "step" = one pass of the hot path (BertModel encoder + all heads) over one synthetic batch of
+36 regions x 2048 features + 36 tokens, model bert_base_6layer_6conect.json, random (seeded) weights,
+inputs resident in HBM before the timed region. Prints ONE JSON line on rank 0.
+
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); per-GPU batch is fixed
+(weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "vilbert-multi-task_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIG = "bert_base_6layer_6conect.json"
+N_TOK, N_REG = 36, 36
+PEAK_FP32_MFMA_TFLOPS = 157.3  # gfx950 v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
+
+
+def model_flops_per_sample(cfg, T, R, heads="vltasks"):
+    """Algorithmic forward FLOPs per sample (2 per MAC, no padding) - BASELINE.md section 2."""
+    H, I, Hv, Iv, Hb = (cfg["hidden_size"], cfg["intermediate_size"], cfg["v_hidden_size"],
+                        cfg["v_intermediate_size"], cfg["bi_hidden_size"])
+    Lt, Lv, Lc = cfg["num_hidden_layers"], cfg["v_num_hidden_layers"], len(cfg["v_biattention_id"])
+    V = cfg["vocab_size"]
+    text = Lt * (2 * T * (4 * H * H + 2 * H * I) + 4 * T * T * H)
+    image = Lv * (2 * R * (4 * Hv * Hv + 2 * Hv * Iv) + 4 * R * R * Hv)
+    conn = Lc * (2 * (3 * R * Hv * Hb + 3 * T * H * Hb + R * Hb * Hv + T * Hb * H + 2 * R * Hv * Iv + 2 * T * H * I)
+                 + 8 * T * R * Hb)
+    emb = 2 * R * (cfg["v_feature_size"] + 5) * Hv
+    pool = 2 * (H + Hv) * Hb
+    bert = text + image + conn + emb + pool
+    pre_heads = 2 * T * (H * H + H * V) + 2 * R * (Hv * Hv + Hv * cfg["v_target_size"]) + 2 * Hb * 2
+    total = bert + pre_heads
+    if heads == "vltasks":
+        total += 2 * (Hb * 2 * Hb + 2 * Hb * 3129) + 2 * (Hb * 2 * Hb + 2 * Hb * 1533) \
+            + (2 * (2 * Hb * 2 * Hb + 2 * Hb * 2)) / 2 + 2 * Hb * 4 + 2 * R * Hv + 2 * T * H
+    return bert, total
+
+
+def build_model(cfg, kind, device):
+    from oracle import synth
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining, VILBertForVLTasks
+    c = BertConfig.from_dict(cfg)
+    model = VILBertForVLTasks(c, num_labels=1) if kind == "vltasks" else BertForMultiModalPreTraining(c)
+    model.load_state_dict(synth.make_state_dict(cfg, kind))
+    return model.to(device)
+
+
+def cpu_baseline(cfg, mode, budget_s=20.0):
+    """The oracle (CPU restatement of the reference forward, oracle/vilbert_oracle.py) timed on this
+    host's cores on a bounded sample of the same workload. Reported, never the product path."""
+    from oracle import synth, vilbert_oracle as vo
+    torch.set_num_threads(os.cpu_count())
+    sd = synth.make_state_dict(cfg, "vltasks")
+    B = 16
+    x = synth.make_inputs(cfg, B, N_TOK, N_REG, ragged=False)
+    args = (x["input_ids"], x["image_feat"], x["image_loc"], x["token_type_ids"], x["attention_mask"],
+            x["image_attention_mask"], x["co_attention_mask"])
+    times = []
+    with torch.no_grad():
+        vo.vltasks_forward(sd, cfg, *args)  # warm-up
+        t_start = time.perf_counter()
+        while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 20):
+            t0 = time.perf_counter()
+            vo.vltasks_forward(sd, cfg, *args)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 2), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle/vilbert_oracle.py forward (VILBertForVLTasks, all heads), batch %d x %d iterations, "
+                      "median; torch %s CPU fp32, %d threads" % (B, len(times), torch.__version__, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from oracle import synth
+    from vilbert import ops
+    cfg = synth.load_config(CONFIG)
+    B = args.batch
+    x = synth.make_inputs(cfg, B, N_TOK, N_REG, seed=7 + rank, ragged=False)
+    names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+             "co_attention_mask"]
+    inputs = tuple(x[n].to(device) for n in names)
+
+    if args.mode == "fwd":
+        model = build_model(cfg, "vltasks", device).eval()
+
+        def step():
+            with torch.no_grad():
+                return model(*inputs)
+    else:
+        raise SystemExit("--mode train is not available yet")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Roofline of the dominant kernel (the fp32-MFMA GEMM family, ~99 % of the FLOPs): every
+    # vb_linear_fwd launch of extra profiled steps is bracketed with HIP events on the launch stream.
+    prof_steps = 2
+    ops.profile_linear(True)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    gemm_ms, gemm_flops, gemm_launches = ops.profile_linear(False)
+
+    if rank == 0:
+        bert_f, total_f = model_flops_per_sample(cfg, N_TOK, N_REG, "vltasks")
+        mult = 1 if args.mode == "fwd" else 3
+        sps = world * B * args.steps / elapsed
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        line = {
+            "metric": "samples/sec (36 regions, 36 tokens) ViLBERT-base 6L/6C %s" %
+                      ("forward" if args.mode == "fwd" else "fwd+bwd"),
+            "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded 36x2048 region features + 36 token ids, random-init weights)",
+            "config": {"workload": "%s %s, VILBertForVLTasks incl. all heads, batch %d per GPU, T=%d R=%d" %
+                                   (CONFIG, "forward-only (eval, no_grad)" if args.mode == "fwd"
+                                    else "train step", B, N_TOK, N_REG),
+                       "per_gpu_batch": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world,
+                       "gflop_per_sample_model": round(mult * total_f / 1e9, 3),
+                       "gflop_per_sample_bertmodel": round(mult * bert_f / 1e9, 3)},
+            "model_tflops": round(sps / world * mult * total_f / 1e12, 2),
+            "model_frac_of_fp32_mfma_peak": round(sps / world * mult * total_f / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": gemm_launches // prof_steps,
+                         "avg_launch_us": round(1e3 * gemm_ms / max(gemm_launches, 1), 2),
+                         "flops_per_launch_avg": round(gemm_flops / max(gemm_launches, 1), 0)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.mode)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

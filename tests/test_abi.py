@@ -1,0 +1,89 @@
+"""CPU-side checks of the C-ABI boundary: the shared library builds, loads and exports exactly the
+symbols include/vilbert_hip.h declares, the ctypes mirror matches the header, and the product path
+refuses to run without a GPU (no CPU fallback). No compute is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vilbert_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vb_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__
+    __graft_entry__.build()
+    from vilbert import _native
+    return _native
+
+
+def test_header_declares_the_expected_entry_points():
+    assert _declared() == sorted([
+        "vb_abi_version", "vb_error_string", "vb_linear_fwd", "vb_layernorm_fwd", "vb_text_embed_ln_fwd",
+        "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
+
+
+EXTRA_DECLS = []
+
+
+def test_library_exports_every_declared_symbol(native):
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert sorted(native.SIGNATURES) == _declared()
+    nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (vb_[a-z0-9_]+)", nm)))
+    assert exported == _declared()
+
+
+def test_abi_version_and_error_strings(native):
+    lib = native.lib()
+    assert lib.vb_abi_version() == 1
+    assert lib.vb_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4):
+        assert lib.vb_error_string(code).startswith(b"VB_E_")
+
+
+def test_struct_layouts_match_the_header(native):
+    # field order / count of the ctypes mirrors against the typedefs in the header
+    text = open(HEADER).read()
+    for struct, mirror in (("vb_linear_args", native.LinearArgs), ("vb_attention_args", native.AttentionArgs)):
+        body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", text))[struct]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.sub(r"\[.*\]", "", part.strip().split()[-1].lstrip("*")))
+        assert names == [f[0] for f in mirror._fields_], struct
+
+
+def test_argument_errors_do_not_need_a_gpu(native):
+    lib = native.lib()
+    assert lib.vb_linear_fwd(None, None) == -1
+    assert lib.vb_attention_fwd(None, None) == -1
+    assert lib.vb_layernorm_fwd(None, 0, 0, None, None, None, None, 0.0, None, None, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback(native):
+    from oracle import synth
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg = synth.tiny_config()
+    model = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1).eval()
+    x = synth.make_inputs(cfg, 2, 5, 4)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        with torch.no_grad():
+            model(x["input_ids"], x["image_feat"], x["image_loc"], x["token_type_ids"], x["attention_mask"],
+                  x["image_attention_mask"])

@@ -1,0 +1,234 @@
+"""Per-kernel parity on the GPU: each C-ABI entry point against an fp64 torch restatement of the
+reference arithmetic it replaces (tolerances are fp32-roundoff class, far inside the 1e-4 bar)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vilbert import ops as _ops
+    return _ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def _gelu64(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _close(got, want64, rtol=2e-5, atol=2e-5):
+    got = got.detach().cpu().double()
+    err = (got - want64).abs()
+    bound = atol + rtol * want64.abs()
+    assert got.shape == want64.shape
+    assert torch.isfinite(got).all()
+    assert (err <= bound).all(), "max err %.3e (max |ref| %.3e)" % (err.max().item(), want64.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (128, 128, 32),      # exactly one tile, one k step
+    (256, 384, 768),     # several tiles
+    (36 * 8, 768, 768),  # config-1 text shape, ragged M
+    (100, 200, 52),      # ragged everywhere (K % 32 != 0, N % 128 != 0)
+    (1, 1, 4),           # degenerate
+    (77, 3129, 64),      # wide ragged N (VQA head width)
+    (130, 1024, 2048),   # image embedding K
+])
+def test_linear_plain(ops, M, N, K):
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
+    y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()])
+    _close(y, x.double() @ w.double().t() + b.double())
+
+
+def test_linear_is_transpose_detecting(ops):
+    # asymmetric A = I-like check: y = x @ w.T with x = one-hot rows picks rows of w.T
+    K, N = 64, 160
+    x = torch.zeros(K, K)
+    x[torch.arange(K), torch.arange(K)] = 1.0
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1000.0
+    y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [None])
+    _close(y, w.double().t(), 1e-6, 1e-6)
+
+
+def test_linear_unaligned_k_scalar_path(ops):
+    # K = 5 (image location embeddings) takes the scalar loader
+    x, w, b = _rand(73, 5, seed=4), _rand(96, 5, seed=5), _rand(96, seed=6)
+    y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()])
+    _close(y, x.double() @ w.double().t() + b.double())
+
+
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_linear_act_residual_preact(ops, act):
+    M, N, K = 200, 256, 96
+    x, w, b, r = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1), _rand(N, seed=9), _rand(M, N, seed=10)
+    y, pre = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()], act=act, residual=r.cuda(), want_preact=True)
+    pre64 = x.double() @ w.double().t() + b.double()
+    act64 = _gelu64(pre64) if act == "gelu" else torch.relu(pre64)
+    _close(pre, pre64)
+    _close(y, act64 + r.double())
+
+
+def test_linear_three_segments_qkv(ops):
+    M, H, K = 36 * 5, 128, 192
+    x = _rand(M, K, seed=11)
+    ws = [_rand(H, K, seed=20 + i, scale=0.1) for i in range(3)]
+    bs = [_rand(H, seed=30 + i) for i in range(3)]
+    y, _ = ops.linear_fwd(x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs])
+    want = torch.cat([x.double() @ w.double().t() + b.double() for w, b in zip(ws, bs)], dim=1)
+    _close(y, want)
+
+
+def test_linear_first_token_row_stride(ops):
+    B, S, H, N = 6, 9, 64, 48
+    h = _rand(B, S, H, seed=12).cuda()
+    w, b = _rand(N, H, seed=13), _rand(N, seed=14)
+    y, _ = ops.linear_fwd(h[:, 0], [w.cuda()], [b.cuda()], act="relu")
+    _close(y, torch.relu(h[:, 0].cpu().double() @ w.double().t() + b.double()))
+
+
+def test_linear_errors(ops):
+    x = _rand(4, 8).cuda()
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(x, [_rand(4, 7).cuda()], [None])
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(x.cpu(), [_rand(4, 8).cuda()], [None])
+    with pytest.raises(RuntimeError):  # segments must be 128-aligned
+        ops.linear_fwd(x, [_rand(4, 8).cuda(), _rand(4, 8).cuda()], [None, None])
+
+
+def _ln64(x, g, b, eps=1e-12):
+    u = x.mean(-1, keepdim=True)
+    s = (x - u).pow(2).mean(-1, keepdim=True)
+    return g * ((x - u) / torch.sqrt(s + eps)) + b
+
+
+@pytest.mark.parametrize("cols", [64, 96, 768, 1024, 2048, 4096])
+def test_layernorm(ops, cols):
+    x, x2 = _rand(37, cols, seed=1, scale=3.0) + 0.7, _rand(37, cols, seed=2)
+    g, b = 1 + 0.1 * _rand(cols, seed=3), 0.1 * _rand(cols, seed=4)
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), 1e-12, x2.cuda(), want_stats=True)
+    s = x.double() + x2.double()
+    _close(y, _ln64(s, g.double(), b.double()))
+    _close(mean, s.mean(-1))
+    _close(rstd, 1.0 / torch.sqrt(s.var(-1, unbiased=False) + 1e-12), 1e-5, 1e-6)
+    y1, _, _ = ops.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), 1e-12)
+    _close(y1, _ln64(x.double(), g.double(), b.double()))
+
+
+def test_layernorm_constant_row_is_finite(ops):
+    x = torch.full((3, 64), 2.5)
+    g, b = torch.ones(64), torch.zeros(64)
+    y, _, _ = ops.layernorm_fwd(x.cuda(), g.cuda(), b.cuda(), 1e-12)
+    assert torch.isfinite(y).all() and y.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("task", [False, True])
+def test_text_embedding(ops, task):
+    B, T, H, V = 5, 11, 96, 50
+    g0 = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (B, T), generator=g0)
+    seg = torch.randint(0, 2, (B, T), generator=g0)
+    word, pos, typ = _rand(V, H, seed=1), _rand(40, H, seed=2), _rand(2, H, seed=3)
+    temb, tid = _rand(20, H, seed=4), torch.randint(0, 20, (B, 1), generator=g0)
+    g, b = 1 + 0.1 * _rand(H, seed=5), 0.1 * _rand(H, seed=6)
+    out, _, _ = ops.text_embed_ln_fwd(ids.cuda(), seg.cuda(), word.cuda(), pos.cuda(), typ.cuda(), g.cuda(),
+                                      b.cuda(), 1e-12, tid.cuda() if task else None, temb.cuda() if task else None)
+    e = word.double()[ids] + pos.double()[torch.arange(T)][None] + typ.double()[seg]
+    if task:
+        e = torch.cat([e[:, :1], temb.double()[tid], e[:, 1:]], dim=1)
+    _close(out, _ln64(e, g.double(), b.double()))
+
+
+def test_image_embedding(ops):
+    B, R, H = 4, 9, 1024
+    proj, loc = _rand(B, R, H, seed=1), torch.rand(B, R, 5, generator=torch.Generator().manual_seed(2))
+    wl, bl = _rand(H, 5, seed=3), _rand(H, seed=4)
+    g, b = 1 + 0.1 * _rand(H, seed=5), 0.1 * _rand(H, seed=6)
+    out, _, _ = ops.image_embed_ln_fwd(proj.cuda(), loc.cuda(), wl.cuda(), bl.cuda(), g.cuda(), b.cuda(), 1e-12)
+    s = proj.double() + loc.double() @ wl.double().t() + bl.double()
+    _close(out, _ln64(s, g.double(), b.double()))
+
+
+def test_additive_mask(ops):
+    m = torch.tensor([[1, 1, 0, 0], [1, 0, 0, 1]])
+    want = (1.0 - m.double()) * -10000.0
+    _close(ops.additive_mask(m.cuda()), want, 0, 0)
+    _close(ops.additive_mask(m.float().cuda()), want, 0, 0)
+    _close(ops.additive_mask(m.int().cuda()), want, 0, 0)
+
+
+def _attn64(q, k, v, mask_add, heads):
+    B, Sq, H = q.shape
+    d = H // heads
+    sp = lambda t: t.double().view(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3)
+    s = sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(d)
+    if mask_add is not None:
+        s = s + mask_add.double().view(mask_add.shape[0], 1, 1, -1)
+    p = torch.softmax(s, -1)
+    ctx = (p @ sp(v)).permute(0, 2, 1, 3).reshape(max(q.shape[0], k.shape[0]), Sq, H)
+    return ctx, p
+
+
+@pytest.mark.parametrize("heads,d,Sq,Sk", [
+    (12, 64, 36, 36),    # text self-attention
+    (8, 128, 36, 36),    # image self-attention / co-attention
+    (8, 128, 21, 37),    # co-attention, text queries over 37 regions
+    (2, 32, 9, 7),       # tiny test config
+    (3, 32, 1, 1),       # single token
+    (4, 64, 50, 101),    # > 3 key tiles (NT = 8)
+    (2, 128, 33, 306),   # longest region count in the task table (NT = 20)
+    (2, 64, 256, 256),
+])
+def test_attention_from_fused_qkv(ops, heads, d, Sq, Sk):
+    B, H = 3, heads * d
+    g = torch.Generator().manual_seed(5)
+    qsrc = torch.randn(B, Sq, 3 * H, generator=g)
+    ksrc = qsrc if Sq == Sk else torch.randn(B, Sk, 3 * H, generator=g)
+    lens = torch.randint(1, Sk + 1, (B,), generator=g)
+    mask = (torch.arange(Sk)[None] < lens[:, None]).float()
+    madd = (1.0 - mask) * -10000.0
+    qd, kd = qsrc.cuda(), ksrc.cuda()
+    ctx, probs = ops.attention_fwd(qd[..., :H], kd[..., H:2 * H], kd[..., 2 * H:], madd.cuda(), heads,
+                                   want_probs=True)
+    want_ctx, want_p = _attn64(qsrc[..., :H], ksrc[..., H:2 * H], ksrc[..., 2 * H:], madd, heads)
+    _close(ctx, want_ctx)
+    _close(probs, want_p, 2e-5, 1e-7)
+    ctx2, none = ops.attention_fwd(qd[..., :H], kd[..., H:2 * H], kd[..., 2 * H:], None, heads)
+    assert none is None
+    _close(ctx2, _attn64(qsrc[..., :H], ksrc[..., H:2 * H], ksrc[..., 2 * H:], None, heads)[0])
+
+
+def test_attention_query_broadcast(ops):
+    # one caption against many images (eval_retrieval): q batch 1, k/v batch 5
+    heads, d, T, R, Bn = 8, 128, 12, 36, 5
+    H = heads * d
+    g = torch.Generator().manual_seed(6)
+    q, k, v = torch.randn(1, T, H, generator=g), torch.randn(Bn, R, H, generator=g), torch.randn(Bn, R, H, generator=g)
+    madd = torch.zeros(Bn, R)
+    madd[:, 30:] = -10000.0
+    ctx, _ = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), madd.cuda(), heads)
+    _close(ctx, _attn64(q.expand(Bn, T, H), k, v, madd, heads)[0])
+
+
+def test_attention_fully_masked_row_matches_reference_semantics(ops):
+    # additive -10000 (not -inf): an all-masked row is a uniform softmax, as in the reference
+    heads, d, S = 2, 64, 5
+    g = torch.Generator().manual_seed(7)
+    q, k, v = (torch.randn(1, S, heads * d, generator=g) for _ in range(3))
+    madd = torch.full((1, S), -10000.0)
+    ctx, _ = ops.attention_fwd(q.cuda(), k.cuda(), v.cuda(), madd.cuda(), heads)
+    _close(ctx, _attn64(q, k, v, madd, heads)[0])
+
+
+def test_attention_range_error(ops):
+    q = torch.zeros(1, 4, 64).cuda()
+    k = torch.zeros(1, 400, 64).cuda()
+    with pytest.raises(RuntimeError):
+        ops.attention_fwd(q, k, k, None, 1)

@@ -1,0 +1,285 @@
+// fp32 GEMM family on v_mfma_f32_32x32x2_f32 (exact-fp32 matrix cores, 157.3 TFLOP/s peak on
+// gfx950) with fused epilogues. One kernel template covers the three operand layouts the
+// encoder needs:
+//   forward  (NT)  C[M,N] = A[M,K] . W[N,K]^T        A k-contiguous,  B k-contiguous
+//   dgrad    (NN)  dX[M,K'] = dY[M,N'] . W[N',K']    A k-contiguous,  B j-contiguous
+//   wgrad    (TN)  dW[N',K'] = dY[M,N']^T . X[M,K']  A i-contiguous,  B j-contiguous
+//
+// Block = 256 threads = 4 waves (one per SIMD), block tile 128x128, K step 32, each wave owns a
+// 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs). LDS is double buffered
+// (2 x 36 KiB -> two blocks per CU, i.e. two waves per SIMD so one block's barrier / epilogue is
+// covered by the other's MFMAs). Global -> register -> LDS staging: the loads for K tile t+1 are
+// issued before the 64 MFMAs (4096 matrix-pipe cycles) of tile t and written to the other LDS
+// buffer after them; one barrier per K tile.
+//
+// LDS layouts (floats):
+//   k-contiguous operand: [128 rows][36]  (32 + 4 pad): 16-lane ds_read_b128 groups hit 16
+//       distinct 16-B slots (row stride 36 dwords = 9 slots, odd) -> conflict free.
+//   row-contiguous operand: [32 k][132]: ds_read_b32, lanes = consecutive rows -> conflict free.
+// MFMA operand convention (32x32x2): lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].
+// The contraction order inside a K step is permuted (lane half `hi` owns k = 8c + 4hi + e) so that
+// a k-contiguous operand is fetched with one ds_read_b128 per four MFMAs; A and B use the same
+// permutation, which only reorders the fp32 summation.
+//
+// Workgroup -> tile map is XCD aware: block b runs on XCD b % 8, so XCD x gets a contiguous run
+// of logical tiles (N fastest) and the blocks sharing an A panel share one L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KC_LD = 36;    // k-contiguous LDS row stride
+constexpr int RC_LD = 132;   // row-contiguous LDS row stride
+constexpr int OPER_SZ = 128 * KC_LD;          // 4608 floats (>= 32 * 132 = 4224)
+constexpr int STAGE_SZ = 2 * OPER_SZ;         // A + B
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_SZ * 4;  // 73,728 B
+
+struct GemmP {
+    int M, N, K;
+    const float* A; long lda;
+    const float* B[VB_MAX_SEGMENTS]; long ldb; int bseg;
+    const float* bias[VB_MAX_SEGMENTS];
+    float* C; long ldc;
+    const float* R; long ldr;
+    float* P; long ldp;
+    int act;
+    int accumulate;       // C += result
+    int tiles_m, tiles_n;
+    int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
+};
+
+// Stage one 128 x 32 operand tile into registers (4 float4 per thread).
+// KC: global [rows][ld] with k contiguous.  RC: global [k][ld] with rows contiguous.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void load_tile(f32x4 (&reg)[4], const float* __restrict__ base, long ld,
+                                          int row0, int nrows, int k0, int K, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = tid + 256 * it;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (KC) {
+            const int row = row0 + (f >> 3), k = k0 + (f & 7) * 4;
+            if (row < nrows) {
+                const float* g = base + (long)row * ld + k;
+                if (VEC) {
+                    if (k < K) v = *reinterpret_cast<const f32x4*>(g);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < K) v[e] = g[e];
+                }
+            }
+        } else {
+            const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
+            if (k < K) {
+                const float* g = base + (long)k * ld + row;
+                if (VEC) {
+                    if (row < nrows) v = *reinterpret_cast<const f32x4*>(g);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e < nrows) v[e] = g[e];
+                }
+            }
+        }
+        reg[it] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&reg)[4], int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = tid + 256 * it;
+        const int off = KC ? (f >> 3) * KC_LD + (f & 7) * 4 : (f >> 5) * RC_LD + (f & 31) * 4;
+        *reinterpret_cast<f32x4*>(s + off) = reg[it];
+    }
+}
+
+template <bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap of the linear block id (guide T1).
+    const int nb = p.tiles_m * p.tiles_n;
+    int logical;
+    {
+        const int b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (logical / p.tiles_n) * BM;
+    const int n0 = (logical % p.tiles_n) * BN;
+
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int kt_begin = blockIdx.y * p.ktiles_per_split;
+    const int kt_end = min(kt_total, kt_begin + p.ktiles_per_split);
+    if (kt_begin >= kt_end) return;
+
+    // B segment: along N for a k-contiguous B (weights stacked along out features), along K for
+    // a row-contiguous B (dgrad through stacked weights).
+    const float* Bbase = p.B[0];
+    int b_row_off = 0;
+    if (B_KC) {
+        const int s = n0 / p.bseg;
+        Bbase = p.B[s];
+        b_row_off = s * p.bseg;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+
+    auto load_ab = [&](int kt) {
+        const int k0 = kt * BK;
+        load_tile<A_KC, VEC>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
+        if (B_KC) {
+            load_tile<true, VEC>(rb, Bbase, p.ldb, n0 - b_row_off, p.bseg, k0, p.K, tid);
+        } else {
+            const int s = k0 / p.bseg;
+            load_tile<false, VEC>(rb, p.B[s], p.ldb, n0, p.N, k0 - s * p.bseg,
+                                  min(p.bseg, p.K - s * p.bseg), tid);
+        }
+    };
+
+    load_ab(kt_begin);
+    store_tile<A_KC>(smem, ra, tid);
+    store_tile<B_KC>(smem + OPER_SZ, rb, tid);
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const float* sA = smem + cur * STAGE_SZ;
+        const float* sB = sA + OPER_SZ;
+        const bool more = kt + 1 < kt_end;
+        if (more) load_ab(kt + 1);
+
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (A_KC) {
+                    af[t] = *reinterpret_cast<const f32x4*>(
+                        sA + (wm * 64 + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        af[t][e] = sA[(kc * 8 + hi * 4 + e) * RC_LD + wm * 64 + t * 32 + l31];
+                }
+                if (B_KC) {
+                    bf[t] = *reinterpret_cast<const f32x4*>(
+                        sB + (wn * 64 + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        bf[t][e] = sB[(kc * 8 + hi * 4 + e) * RC_LD + wn * 64 + t * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                        acc[i][j], 0, 0, 0);
+        }
+
+        if (more) {
+            float* dA = smem + (cur ^ 1) * STAGE_SZ;
+            store_tile<A_KC>(dA, ra, tid);
+            store_tile<B_KC>(dA + OPER_SZ, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    const bool split = gridDim.y > 1;
+    const bool lead = blockIdx.y == 0;  // bias / residual are added by one split only
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= p.N) continue;
+        float bv = 0.f;
+        {
+            const int s = col / p.bseg;  // bias follows the N segmentation of a k-contiguous B
+            const float* bp = B_KC ? p.bias[s] : p.bias[0];
+            if (bp != nullptr && lead) bv = bp[B_KC ? col - s * p.bseg : col];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
+                if (p.act == VB_ACT_GELU) v = gelu_erf(v);
+                else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
+                float* c = p.C + (long)row * p.ldc + col;
+                if (split) unsafeAtomicAdd(c, v);
+                else if (p.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+int launch_gemm(hipStream_t st, const GemmP& p, bool vec, int splits) {
+    dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
+    // > 64 KiB of dynamic LDS needs the attribute once per kernel (per process).
+    static bool attr_done[2] = {false, false};
+    auto kv = gemm_f32_kernel<A_KC, B_KC, true>;
+    auto ks = gemm_f32_kernel<A_KC, B_KC, false>;
+    auto k = vec ? kv : ks;
+    if (!attr_done[vec]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done[vec] = true;
+    }
+    hipLaunchKernelGGL(k, grid, block, GEMM_LDS_BYTES, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
+    if (a == nullptr || a->A == nullptr || a->C == nullptr) return VB_E_BADARG;
+    if (a->M <= 0 || a->K <= 0 || a->seg_n <= 0) return VB_E_BADARG;
+    if (a->nseg < 1 || a->nseg > VB_MAX_SEGMENTS) return VB_E_SEGMENT;
+    if (a->nseg > 1 && (a->seg_n % BN) != 0) return VB_E_SEGMENT;
+    if (a->act < VB_ACT_NONE || a->act > VB_ACT_RELU) return VB_E_BADARG;
+    GemmP p{};
+    p.M = a->M; p.K = a->K; p.N = a->nseg * a->seg_n;
+    p.A = a->A; p.lda = a->lda;
+    p.ldb = a->ldw; p.bseg = a->seg_n;
+    bool vec = (a->K % 4 == 0) && (a->lda % 4 == 0) && (a->ldw % 4 == 0) && vb_aligned16(a->A);
+    for (int s = 0; s < a->nseg; ++s) {
+        if (a->W[s] == nullptr) return VB_E_SEGMENT;
+        p.B[s] = a->W[s];
+        p.bias[s] = a->bias[s];
+        vec = vec && vb_aligned16(a->W[s]);
+    }
+    p.C = a->C; p.ldc = a->ldc;
+    p.R = a->residual; p.ldr = a->ldr;
+    p.P = a->preact; p.ldp = a->ldp;
+    p.act = a->act; p.accumulate = 0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.ktiles_per_split = (p.K + BK - 1) / BK;
+    return launch_gemm<true, true>(static_cast<hipStream_t>(stream), p, vec, 1);
+}

@@ -1,0 +1,264 @@
+// Row kernels (HBM-bound): LayerNorm, fused text embedding gather + LayerNorm, fused image
+// location projection + LayerNorm, additive-mask conversion.
+//
+// One 64-lane wave owns one row (768 / 1024 / 2048 columns = 3 / 4 / 8 float4 per lane, read and
+// written as 16-byte coalesced accesses); the row stays in registers between the statistics
+// passes, so every element is read from HBM once and written once. Statistics are two-pass
+// (mean, then the mean of squared deviations) exactly as the reference computes them.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
+
+// y = gamma * (x - mean) * rstd + beta, TF style (biased variance, eps inside the sqrt)
+// reference vilbert.py:313-317
+template <int NV>
+__device__ __forceinline__ void ln_finish(f32x4 (&x)[NV], int n_cols, int lane, const float* gamma,
+                                          const float* beta, float eps, float* yrow, float* mean_out,
+                                          float* rstd_out) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < n_cols) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)n_cols;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < n_cols) {
+            x[i] -= mean;
+            v += (x[i][0] * x[i][0] + x[i][1] * x[i][1]) + (x[i][2] * x[i][2] + x[i][3] * x[i][3]);
+        }
+    }
+    const float var = wave_sum(v) / (float)n_cols;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        if (mean_out != nullptr) *mean_out = mean;
+        if (rstd_out != nullptr) *rstd_out = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < n_cols) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
+            *reinterpret_cast<f32x4*>(yrow + col) = g * (x[i] * rstd) + b;
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(long rows, int n_cols, const float* __restrict__ x,
+                                                        const float* __restrict__ x2,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ y, float* mean, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * n_cols;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < n_cols) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + col);
+            if (x2 != nullptr) v[i] += *reinterpret_cast<const f32x4*>(x2 + row * n_cols + col);
+        }
+    }
+    ln_finish<NV>(v, n_cols, lane, gamma, beta, eps, y + row * n_cols, mean ? mean + row : nullptr,
+                  rstd ? rstd + row : nullptr);
+}
+
+// reference vilbert.py:346-367
+template <int NV>
+__global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, int hidden,
+                                                         const int64_t* __restrict__ ids,
+                                                         const int64_t* __restrict__ seg, int pos_offset,
+                                                         const float* __restrict__ word,
+                                                         const float* __restrict__ pos,
+                                                         const float* __restrict__ type,
+                                                         const int64_t* __restrict__ task_ids,
+                                                         const float* __restrict__ task_emb,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ out, float* mean, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const int n_out = n_tok + (task_ids != nullptr ? 1 : 0);
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= (long)batch * n_out) return;
+    const int b = (int)(row / n_out), t_out = (int)(row % n_out);
+    // with task tokens: output 0 <- token 0, output 1 <- task embedding, output t <- token t - 1
+    const bool is_task = task_ids != nullptr && t_out == 1;
+    const int t = (task_ids != nullptr && t_out >= 2) ? t_out - 1 : t_out;
+    const float *w = nullptr, *pp = nullptr, *ty = nullptr;
+    if (is_task) {
+        w = task_emb + task_ids[b] * hidden;
+    } else {
+        w = word + ids[(long)b * n_tok + t] * hidden;
+        pp = pos + (long)(t + pos_offset) * hidden;
+        ty = type + seg[(long)b * n_tok + t] * hidden;
+    }
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < hidden) {
+            v[i] = *reinterpret_cast<const f32x4*>(w + col);
+            if (!is_task) {
+                // words + position + token_type, in the reference's order (vilbert.py:355)
+                v[i] += *reinterpret_cast<const f32x4*>(pp + col);
+                v[i] += *reinterpret_cast<const f32x4*>(ty + col);
+            }
+        }
+    }
+    ln_finish<NV>(v, hidden, lane, gamma, beta, eps, out + row * hidden, mean ? mean + row : nullptr,
+                  rstd ? rstd + row : nullptr);
+}
+
+// reference vilbert.py:1421-1432 (the 5 -> hidden location projection, the sum and the LayerNorm)
+template <int NV>
+__global__ __launch_bounds__(256) void image_embed_kernel(long rows, int hidden,
+                                                          const float* __restrict__ feat_proj,
+                                                          const float* __restrict__ loc,
+                                                          const float* __restrict__ w_loc,
+                                                          const float* __restrict__ b_loc,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ out, float* mean, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float l[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) l[j] = loc[row * 5 + j];
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < hidden) {
+            f32x4 lp = *reinterpret_cast<const f32x4*>(b_loc + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* wr = w_loc + (long)(col + e) * 5;
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) a = fmaf(l[j], wr[j], a);
+                lp[e] += a;
+            }
+            v[i] = *reinterpret_cast<const f32x4*>(feat_proj + row * hidden + col) + lp;
+        }
+    }
+    ln_finish<NV>(v, hidden, lane, gamma, beta, eps, out + row * hidden, mean ? mean + row : nullptr,
+                  rstd ? rstd + row : nullptr);
+}
+
+template <typename T>
+__global__ void additive_mask_kernel(long n, const T* __restrict__ mask, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // reference vilbert.py:1353,1362: (1.0 - mask) * -10000.0
+    if (i < n) out[i] = (1.0f - (float)mask[i]) * -10000.0f;
+}
+
+inline int nv_for(int n_cols) { return (n_cols + 255) / 256; }
+
+#define VB_NV_DISPATCH(nv, CALL)             \
+    switch (nv) {                            \
+        case 1: { constexpr int NV = 1; CALL; } break; \
+        case 2: { constexpr int NV = 2; CALL; } break; \
+        case 3: { constexpr int NV = 3; CALL; } break; \
+        case 4: { constexpr int NV = 4; CALL; } break; \
+        case 5: case 6: case 7: case 8: { constexpr int NV = 8; CALL; } break; \
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: \
+                { constexpr int NV = 16; CALL; } break; \
+        default: { constexpr int NV = 32; CALL; } break; \
+    }
+
+inline int check_cols(int n_cols) {
+    if (n_cols <= 0) return VB_E_BADARG;
+    if (n_cols % 4 != 0) return VB_E_ALIGN;
+    if (n_cols > VB_MAX_LN_COLS) return VB_E_RANGE;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vb_layernorm_fwd(void* stream, int64_t rows, int32_t n_cols, const float* x, const float* x2,
+                                const float* gamma, const float* beta, float eps, float* y, float* mean,
+                                float* rstd) {
+    if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || rows <= 0) return VB_E_BADARG;
+    if (int e = check_cols(n_cols)) return e;
+    if (!vb_aligned16(x) || !vb_aligned16(y) || !vb_aligned16(gamma) || !vb_aligned16(beta) ||
+        (x2 != nullptr && !vb_aligned16(x2)))
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, (long)rows,
+                                                      n_cols, x, x2, gamma, beta, eps, y, mean, rstd));
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden,
+                                    const int64_t* ids, const int64_t* seg, int32_t pos_offset,
+                                    const float* word_emb, const float* pos_emb, const float* type_emb,
+                                    const int64_t* task_ids, const float* task_emb, const float* gamma,
+                                    const float* beta, float eps, float* out, float* mean, float* rstd) {
+    if (ids == nullptr || seg == nullptr || word_emb == nullptr || pos_emb == nullptr || type_emb == nullptr ||
+        gamma == nullptr || beta == nullptr || out == nullptr || batch <= 0 || n_tok <= 0)
+        return VB_E_BADARG;
+    if (task_ids != nullptr && task_emb == nullptr) return VB_E_BADARG;
+    if (int e = check_cols(hidden)) return e;
+    if (!vb_aligned16(word_emb) || !vb_aligned16(pos_emb) || !vb_aligned16(type_emb) || !vb_aligned16(out) ||
+        !vb_aligned16(gamma) || !vb_aligned16(beta) || (task_emb != nullptr && !vb_aligned16(task_emb)))
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long rows = (long)batch * (n_tok + (task_ids != nullptr ? 1 : 0));
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(hidden),
+                   hipLaunchKernelGGL((text_embed_kernel<NV>), grid, block, 0, st, batch, n_tok, hidden, ids, seg,
+                                      pos_offset, word_emb, pos_emb, type_emb, task_ids, task_emb, gamma, beta,
+                                      eps, out, mean, rstd));
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_image_embed_ln_fwd(void* stream, int64_t rows, int32_t hidden, const float* feat_proj,
+                                     const float* loc, const float* w_loc, const float* b_loc,
+                                     const float* gamma, const float* beta, float eps, float* out, float* mean,
+                                     float* rstd) {
+    if (feat_proj == nullptr || loc == nullptr || w_loc == nullptr || b_loc == nullptr || gamma == nullptr ||
+        beta == nullptr || out == nullptr || rows <= 0)
+        return VB_E_BADARG;
+    if (int e = check_cols(hidden)) return e;
+    if (!vb_aligned16(feat_proj) || !vb_aligned16(out) || !vb_aligned16(b_loc) || !vb_aligned16(gamma) ||
+        !vb_aligned16(beta))
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(hidden),
+                   hipLaunchKernelGGL((image_embed_kernel<NV>), grid, block, 0, st, (long)rows, hidden, feat_proj,
+                                      loc, w_loc, b_loc, gamma, beta, eps, out, mean, rstd));
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_additive_mask(void* stream, int64_t n, const void* mask, int32_t mask_is_f32, float* out) {
+    if (mask == nullptr || out == nullptr || n <= 0) return VB_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (mask_is_f32)
+        hipLaunchKernelGGL(additive_mask_kernel<float>, grid, block, 0, st, (long)n,
+                           static_cast<const float*>(mask), out);
+    else
+        hipLaunchKernelGGL(additive_mask_kernel<int64_t>, grid, block, 0, st, (long)n,
+                           static_cast<const int64_t*>(mask), out);
+    VB_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,116 @@
+"""ctypes binding of libvilbert_hip.so (C ABI: include/vilbert_hip.h).
+
+The library is the product's only compute path: there is NO CPU or eager-PyTorch fallback.
+If the shared object is missing, or a tensor is not on a HIP device, the call raises.
+PyTorch is used for device memory (``torch.empty``) and the current stream only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libvilbert_hip.so")
+
+VB_MAX_SEGMENTS = 4
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU}
+
+_c_f32p = ctypes.c_void_p  # device pointers are passed as plain addresses
+
+
+class LinearArgs(ctypes.Structure):
+    """vb_linear_args"""
+    _fields_ = [
+        ("M", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32),
+        ("A", _c_f32p), ("lda", ctypes.c_int64),
+        ("W", _c_f32p * VB_MAX_SEGMENTS), ("ldw", ctypes.c_int64),
+        ("bias", _c_f32p * VB_MAX_SEGMENTS),
+        ("C", _c_f32p), ("ldc", ctypes.c_int64),
+        ("residual", _c_f32p), ("ldr", ctypes.c_int64),
+        ("preact", _c_f32p), ("ldp", ctypes.c_int64),
+        ("act", ctypes.c_int32),
+    ]
+
+
+class AttentionArgs(ctypes.Structure):
+    """vb_attention_args"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("heads", ctypes.c_int32), ("head_dim", ctypes.c_int32),
+        ("n_q", ctypes.c_int32), ("n_k", ctypes.c_int32),
+        ("q_batch", ctypes.c_int32), ("kv_batch", ctypes.c_int32),
+        ("Q", _c_f32p), ("ldq", ctypes.c_int64),
+        ("K", _c_f32p), ("ldk", ctypes.c_int64),
+        ("V", _c_f32p), ("ldv", ctypes.c_int64),
+        ("mask_add", _c_f32p),
+        ("O", _c_f32p), ("ldo", ctypes.c_int64),
+        ("probs", _c_f32p),
+        ("scale", ctypes.c_float),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/vilbert_hip.h one to one (checked by
+# tests/test_abi.py against the header text).
+_I32, _I64, _F32, _P = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+SIGNATURES = {
+    "vb_abi_version": (ctypes.c_int, []),
+    "vb_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
+    "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
+    "vb_text_embed_ln_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
+                                             _F32, _P, _P, _P]),
+    "vb_image_embed_ln_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _F32, _P, _P, _P]),
+    "vb_additive_mask": (ctypes.c_int, [_P, _I64, _P, _I32, _P]),
+    "vb_attention_fwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "libvilbert_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C vilbert-multi-task_amd/csrc`). There is no fallback path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        if handle.vb_abi_version() != 1:
+            raise RuntimeError("libvilbert_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().vb_error_string(code)
+        raise RuntimeError("%s failed: [%d] %s" % (what, code, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_f32(t, what):
+    """Validate a device fp32 tensor and return its address (0 for None)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s: expected a tensor on a HIP device, got %s - the MI355X-native path has no "
+                           "CPU fallback" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s: expected float32, got %s" % (what, t.dtype))
+    return t.data_ptr()
+
+
+def dev_i64(t, what):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+        raise RuntimeError("%s: expected a contiguous int64 tensor on a HIP device" % what)
+    return t.data_ptr()

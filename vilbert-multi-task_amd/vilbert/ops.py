@@ -1,0 +1,207 @@
+"""Tensor-level entry points of the native layer (forward launchers).
+
+Every function here validates its tensors, allocates the outputs with ``torch.empty`` and enqueues
+exactly the kernels of include/vilbert_hip.h on the current stream. No torch arithmetic.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native as N
+
+
+# Optional per-launch timing of the GEMM kernel (bench.py's roofline leg): when enabled every
+# vb_linear_fwd launch is bracketed by HIP events recorded on the launch stream.
+_PROFILE = {"on": False, "events": [], "flops": 0.0}
+
+
+def profile_linear(enable):
+    """enable=True starts collecting; enable=False stops and returns (total_ms, total_flops, launches)."""
+    if enable:
+        _PROFILE.update(on=True, events=[], flops=0.0)
+        return None
+    _PROFILE["on"] = False
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in _PROFILE["events"])
+    out = (ms, _PROFILE["flops"], len(_PROFILE["events"]))
+    _PROFILE["events"] = []
+    return out
+
+
+def _rows(t):
+    """[..., C] -> (rows, C) of a contiguous tensor."""
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
+    """act(x @ cat(weights).T + cat(biases)) (+ residual).
+
+    x: [..., K] (the last dim must be contiguous; a uniform row stride is allowed, e.g. the first-token
+    view ``h[:, 0]`` of the poolers). weights: list of [n, K] with equal n; biases: list of [n] or None.
+    Returns (y [..., nseg*n], preact or None).
+    """
+    if not isinstance(weights, (list, tuple)):
+        weights, biases = [weights], [biases]
+    nseg, seg_n, K = len(weights), weights[0].shape[0], weights[0].shape[1]
+    if x.shape[-1] != K:
+        raise RuntimeError("linear: input has %d features, weight expects %d" % (x.shape[-1], K))
+    # accept [rows..., K] views whose rows are uniformly strided
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K:
+        x2, lda, lead = x, x.stride(0), (x.shape[0],)
+    else:
+        x = _contig(x)
+        lead = tuple(x.shape[:-1])
+        x2, lda = x.view(-1, K), K
+    M = x2.shape[0]
+    n_out = nseg * seg_n
+    y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if want_preact else None
+    a = N.LinearArgs()
+    a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
+    a.A, a.lda = N.dev_f32(x2, "linear input"), lda
+    for s in range(nseg):
+        w = weights[s]
+        if w.shape != (seg_n, K) or not w.is_contiguous():
+            raise RuntimeError("linear: weight segments must be contiguous and equally shaped")
+        a.W[s] = N.dev_f32(w, "linear weight")
+        b = biases[s] if biases is not None else None
+        a.bias[s] = N.dev_f32(b, "linear bias") if b is not None else None
+    a.ldw = K
+    a.C, a.ldc = y.data_ptr(), n_out
+    if residual is not None:
+        residual = _contig(residual)
+        if residual.numel() != M * n_out:
+            raise RuntimeError("linear: residual shape mismatch")
+        a.residual, a.ldr = N.dev_f32(residual, "linear residual"), n_out
+    if pre is not None:
+        a.preact, a.ldp = pre.data_ptr(), n_out
+    a.act = N.ACT_CODES[act]
+    if _PROFILE["on"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd")
+        e1.record()
+        _PROFILE["events"].append((e0, e1))
+        _PROFILE["flops"] += 2.0 * M * n_out * K
+    else:
+        N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd")
+    return y, pre
+
+
+def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
+    x = _contig(x)
+    rows, cols = _rows(x)
+    y = torch.empty_like(x)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if x2 is not None:
+        x2 = _contig(x2)
+        if x2.shape != x.shape:
+            raise RuntimeError("layernorm: x2 shape mismatch")
+    N.check(N.lib().vb_layernorm_fwd(
+        N.stream_ptr(), rows, cols, N.dev_f32(x, "layernorm input"), N.dev_f32(x2, "layernorm x2"),
+        N.dev_f32(gamma, "layernorm weight"), N.dev_f32(beta, "layernorm bias"), eps, y.data_ptr(),
+        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None), "vb_layernorm_fwd")
+    return y, mean, rstd
+
+
+def text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None, task_emb=None,
+                      want_stats=False):
+    ids, seg = _contig(ids), _contig(seg)
+    B, T = ids.shape
+    H = word.shape[1]
+    if T > pos.shape[0]:
+        raise RuntimeError("sequence length %d exceeds max_position_embeddings %d" % (T, pos.shape[0]))
+    n_out = T + (1 if task_ids is not None else 0)
+    out = torch.empty(B, n_out, H, dtype=torch.float32, device=word.device)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(B * n_out, dtype=torch.float32, device=word.device)
+        rstd = torch.empty(B * n_out, dtype=torch.float32, device=word.device)
+    if task_ids is not None:
+        task_ids = _contig(task_ids.view(-1))
+        if task_ids.numel() != B:
+            raise RuntimeError("task_ids must hold one id per sample")
+    N.check(N.lib().vb_text_embed_ln_fwd(
+        N.stream_ptr(), B, T, H, N.dev_i64(ids, "input_ids"), N.dev_i64(seg, "token_type_ids"), 0,
+        N.dev_f32(word, "word_embeddings"), N.dev_f32(pos, "position_embeddings"),
+        N.dev_f32(typ, "token_type_embeddings"), N.dev_i64(task_ids, "task_ids"),
+        N.dev_f32(task_emb, "task_embeddings"), N.dev_f32(gamma, "LayerNorm.weight"),
+        N.dev_f32(beta, "LayerNorm.bias"), eps, out.data_ptr(),
+        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None),
+        "vb_text_embed_ln_fwd")
+    return out, mean, rstd
+
+
+def image_embed_ln_fwd(feat_proj, loc, w_loc, b_loc, gamma, beta, eps, want_stats=False):
+    feat_proj, loc = _contig(feat_proj), _contig(loc)
+    rows, H = _rows(feat_proj)
+    if loc.shape[-1] != 5 or loc.numel() != rows * 5:
+        raise RuntimeError("image_loc must be [..., 5] matching the features")
+    out = torch.empty_like(feat_proj)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=out.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=out.device)
+    N.check(N.lib().vb_image_embed_ln_fwd(
+        N.stream_ptr(), rows, H, N.dev_f32(feat_proj, "image projection"), N.dev_f32(loc, "image_loc"),
+        N.dev_f32(w_loc, "image_location_embeddings.weight"), N.dev_f32(b_loc, "image_location_embeddings.bias"),
+        N.dev_f32(gamma, "LayerNorm.weight"), N.dev_f32(beta, "LayerNorm.bias"), eps, out.data_ptr(),
+        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None),
+        "vb_image_embed_ln_fwd")
+    return out, mean, rstd
+
+
+def additive_mask(mask):
+    """(1 - mask) * -10000 as fp32, same shape (reference vilbert.py:1341-1362)."""
+    mask = _contig(mask)
+    if mask.dtype == torch.float32:
+        is_f32 = 1
+    elif mask.dtype == torch.int64:
+        is_f32 = 0
+    else:
+        mask, is_f32 = mask.to(torch.int64), 0
+    if not mask.is_cuda:
+        raise RuntimeError("attention mask must live on a HIP device - no CPU fallback")
+    out = torch.empty(mask.shape, dtype=torch.float32, device=mask.device)
+    N.check(N.lib().vb_additive_mask(N.stream_ptr(), mask.numel(), mask.data_ptr(), is_f32, out.data_ptr()),
+            "vb_additive_mask")
+    return out
+
+
+def attention_fwd(q, k, v, mask_add, heads, want_probs=False):
+    """q: [Bq, Sq, H*] view, k/v: [Bk, Sk, H*] views (last dim contiguous, uniform row stride, e.g. column
+    slices of a fused [q|k|v] projection); mask_add: [Bk, 1, 1, Sk] or [Bk, Sk] fp32 additive, or None.
+    Bq / Bk may be 1 against a larger batch (broadcast). Returns (ctx [B, Sq, H], probs or None)."""
+    Bq, Sq, H = q.shape
+    Bk, Sk, _ = k.shape
+    B = max(Bq, Bk)
+    d = H // heads
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise RuntimeError("attention: %s must be a row-strided view" % nm)
+    out = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
+    probs = torch.empty(B, heads, Sq, Sk, dtype=torch.float32, device=q.device) if want_probs else None
+    a = N.AttentionArgs()
+    a.batch, a.heads, a.head_dim, a.n_q, a.n_k = B, heads, d, Sq, Sk
+    a.q_batch, a.kv_batch = Bq, Bk
+    a.Q, a.ldq = N.dev_f32(q, "attention q"), q.stride(1)
+    a.K, a.ldk = N.dev_f32(k, "attention k"), k.stride(1)
+    a.V, a.ldv = N.dev_f32(v, "attention v"), v.stride(1)
+    if mask_add is not None:
+        mask_add = _contig(mask_add)
+        if mask_add.numel() != Bk * Sk:
+            raise RuntimeError("attention: mask must hold %d x %d values" % (Bk, Sk))
+        a.mask_add = N.dev_f32(mask_add, "attention mask")
+    a.O, a.ldo = out.data_ptr(), H
+    a.probs = probs.data_ptr() if want_probs else None
+    a.scale = 1.0 / math.sqrt(d)
+    N.check(N.lib().vb_attention_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_attention_fwd")
+    return out, probs
