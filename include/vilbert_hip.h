@@ -7,7 +7,8 @@
  * is therefore the Python class API (vilbert.vilbert.BertConfig / BertModel /
  * BertForMultiModalPreTraining / VILBertForVLTasks); this header is the native layer *below* it.
  * Each entry point replaces the group of torch calls cited next to it (file:line into
- * /root/reference/vilbert/vilbert.py).
+ * /root/reference/vilbert/vilbert.py); the *_bwd entry points replace what torch autograd runs for
+ * the same lines under loss.backward() (train_concap.py:572, train_tasks.py:540).
  *
  * Conventions
  *  - every pointer is a DEVICE pointer to fp32 (ids / masks: int64) unless stated; row-major;
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 1
+#define VB_ABI_VERSION 2
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -59,7 +60,7 @@ const char* vb_error_string(int code);
  * bias[s] (seg_n floats) may be NULL. residual (ldr) may be NULL; when given it is added AFTER
  * the activation (the `dense(x) + input_tensor` of BertSelfOutput/BertOutput).
  * preact (ldp) may be NULL; when given the pre-activation (A.W^T + bias) is also stored
- * (saved for backward). N = nseg*seg_n; when nseg > 1, seg_n must be a multiple of 128.
+ * (saved for backward). N = nseg*seg_n.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t M, K;
@@ -76,6 +77,50 @@ typedef struct {
 int vb_linear_fwd(void* stream, const vb_linear_args* a);
 
 /* ------------------------------------------------------------------------------------------
+ * vb_linear_bwd_input:  dX[M,K] (+)= dY[M, nseg*seg_n] . stack(W)
+ * Gradient of nn.Linear w.r.t. its input (autograd of the lines listed for vb_linear_fwd); the
+ * stacked segments are contracted in one launch. accumulate != 0 adds into dX.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t M, K;
+    int32_t nseg, seg_n;
+    const float* dY;           int64_t ldy;
+    const float* W[VB_MAX_SEGMENTS]; int64_t ldw;
+    float* dX;                 int64_t ldx;
+    int32_t accumulate;
+} vb_linear_bwd_input_args;
+
+int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args* a);
+
+/* ------------------------------------------------------------------------------------------
+ * vb_linear_bwd_weight:  dW[n,K] (+)= dY[:, 0:n]^T . X[M,K]   and   dbias[n] (+)= colsum(dY[:, 0:n])
+ * Gradient of nn.Linear w.r.t. weight and bias of ONE segment (dY points at the segment's first
+ * column, ldy is the full row stride). The contraction over the M rows is split over workgroups and
+ * combined with fp32 atomics. dbias may be NULL. accumulate == 0 zero-fills dW / dbias first.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t M, K, n;
+    const float* dY;           int64_t ldy;
+    const float* X;            int64_t ldx;
+    float* dW;                 int64_t ldw;
+    float* dbias;
+    int32_t accumulate;
+} vb_linear_bwd_weight_args;
+
+int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_args* a);
+
+/* dx = dy * act'(preact) elementwise (n % 4 == 0), act in {VB_ACT_GELU, VB_ACT_RELU}: the backward of
+ * the GEMM epilogue activation (gelu vilbert.py:111-117, ReLU :1114,1129). */
+int vb_act_bwd(void* stream, int64_t n, int32_t act, const float* dy, const float* preact, float* dx);
+
+/* y = x * keep(seed, i) / (1 - p) (+ residual): nn.Dropout (vilbert.py:365,472,515,631,676,847,850,
+ * 1430 ...) optionally fused with the `+ input_tensor` that follows it (:473,516,632,677,852-853).
+ * residual may be NULL. The mask is a pure function of (seed, element index), so calling it again on
+ * the output gradient with the same seed (and no residual) IS the backward. */
+int vb_dropout(void* stream, int64_t n, const float* x, const float* residual, float* y, float p,
+               uint64_t seed);
+
+/* ------------------------------------------------------------------------------------------
  * vb_layernorm_fwd:  y = gamma * (x - mean) / sqrt(var + eps) + beta   per row of n_cols
  *
  * Replaces BertLayerNorm (TF style: biased variance, eps inside the sqrt) - vilbert.py:297-317.
@@ -86,33 +131,49 @@ int vb_layernorm_fwd(void* stream, int64_t rows, int32_t n_cols, const float* x,
                      const float* gamma, const float* beta, float eps, float* y,
                      float* mean, float* rstd);
 
+/* vb_layernorm_bwd: dx, dgamma, dbeta of the above given dy, the normalised INPUT x (= x + x2 of the
+ * forward), and the saved mean / rstd. Deterministic two-stage column reduction through `workspace`
+ * (vb_layernorm_bwd_workspace(rows, n_cols) floats). dgamma / dbeta are overwritten. */
+int64_t vb_layernorm_bwd_workspace(int64_t rows, int32_t n_cols);
+int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
+                     const float* mean, const float* rstd, const float* gamma, float* dx,
+                     float* dgamma, float* dbeta, float* workspace);
+
 /* ------------------------------------------------------------------------------------------
  * vb_text_embed_ln_fwd: LayerNorm(word[ids] + pos[arange + pos_offset] + type[segment_ids])
  *
- * Replaces BertEmbeddings.forward - vilbert.py:346-367 (pos_offset = 2 restates
- * RobertaEmbeddings :379-393). ids / seg: int64 [batch, n_tok]. When task_ids != NULL
- * (config.task_specific_tokens, :358-362) the row task_emb[task_ids[b]] is inserted at output
- * position 1 (it receives no position / type embedding) and the output has n_tok + 1 rows per
- * sample. out: [batch, n_tok (+1), hidden].
+ * Replaces BertEmbeddings.forward - vilbert.py:346-367. pos_offset is 0 for every reference model:
+ * RobertaEmbeddings (:370-393) computes offset ids that its base class then overwrites (:349-352).
+ * ids / seg: int64 [batch, n_tok]. When task_ids != NULL (config.task_specific_tokens, :358-362) the
+ * row task_emb[task_ids[b]] is inserted at output position 1 (it receives no position / type
+ * embedding) and the output has n_tok + 1 rows per sample. out: [batch, n_tok (+1), hidden].
+ * presum (may be NULL) receives the pre-LayerNorm sum (saved for backward).
  * ------------------------------------------------------------------------------------------ */
 int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden,
                          const int64_t* ids, const int64_t* seg, int32_t pos_offset,
                          const float* word_emb, const float* pos_emb, const float* type_emb,
                          const int64_t* task_ids, const float* task_emb,
                          const float* gamma, const float* beta, float eps, float* out,
-                         float* mean, float* rstd);
+                         float* mean, float* rstd, float* presum);
+
+/* vb_text_embed_bwd: scatter-add (fp32 atomics) of dx [batch, n_tok (+1), hidden] - the gradient of
+ * the pre-LayerNorm sum - into the ZERO-FILLED (or accumulating) tables dword / dpos / dtype / dtask.
+ * Word row 0 is nn.Embedding's padding_idx (vilbert.py:330-332) and receives nothing. */
+int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, const int64_t* ids,
+                      const int64_t* seg, const int64_t* task_ids, const float* dx, float* dword,
+                      float* dpos, float* dtype, float* dtask);
 
 /* ------------------------------------------------------------------------------------------
  * vb_image_embed_ln_fwd: LayerNorm(feat_proj + loc . Wloc^T + bloc)
  *
  * Second half of BertImageEmbeddings.forward - vilbert.py:1421-1432: feat_proj [rows, hidden] is
  * the 2048->hidden projection (already holding its bias; produced by vb_linear_fwd), loc is
- * [rows, 5], Wloc is [hidden, 5]. The pre-norm sum is stored to `presum` when non-NULL.
+ * [rows, 5], Wloc is [hidden, 5]. presum (may be NULL) receives the pre-LayerNorm sum.
  * ------------------------------------------------------------------------------------------ */
 int vb_image_embed_ln_fwd(void* stream, int64_t rows, int32_t hidden, const float* feat_proj,
                           const float* loc, const float* w_loc, const float* b_loc,
                           const float* gamma, const float* beta, float eps, float* out,
-                          float* mean, float* rstd);
+                          float* mean, float* rstd, float* presum);
 
 /* ------------------------------------------------------------------------------------------
  * vb_additive_mask: out[i] = (1 - mask[i]) * -10000      (int64 or fp32 -> fp32)
@@ -122,18 +183,23 @@ int vb_image_embed_ln_fwd(void* stream, int64_t rows, int32_t hidden, const floa
 int vb_additive_mask(void* stream, int64_t n, const void* mask, int32_t mask_is_f32, float* out);
 
 /* ------------------------------------------------------------------------------------------
- * vb_attention_fwd: O = softmax(Q K^T * scale + mask) V   per (sample, head), heads merged
+ * vb_attention_fwd: O = dropout(softmax(Q K^T * scale + mask)) V   per (sample, head), heads merged
  *
- * Replaces the score / softmax / context block of BertSelfAttention (vilbert.py:429-449),
+ * Replaces the score / softmax / dropout / context block of BertSelfAttention (vilbert.py:429-449),
  * BertImageSelfAttention (:588-608) and each direction of BertBiAttention (:768-809) including
  * transpose_for_scores (:416-422) and the head merge: Q/K/V are token-major [batch*S, ld] views
  * (typically slices of a fused [q|k|v] projection, hence the separate ld*), head h occupies
  * columns [h*head_dim, (h+1)*head_dim). mask_add: fp32 [kv_batch, n_k] additive mask (may be
  * NULL). q_batch / kv_batch: number of samples behind Q and behind K/V/mask - either equal to
  * `batch` or 1 (broadcast; the 1-caption x N-images case of eval_retrieval, :1042-1053).
- * probs (may be NULL): [batch, heads, n_q, n_k] softmax output (`visualization` /
- * output_all_attention_masks, :451-458). head_dim in {64, 128} (32 also compiled for unit
- * tests); n_k <= VB_MAX_KEYS.
+ * probs (may be NULL): [batch, heads, n_q, n_k] attention probabilities after dropout
+ * (`visualization`, :451-458). lse (may be NULL): [batch, heads, n_q] log-sum-exp of the masked
+ * scores (saved for backward). dropout_p in [0, 1): keep mask = f(seed, element index of probs).
+ * head_dim in {32, 64, 128}; n_k <= VB_MAX_KEYS.
+ *
+ * vb_attention_bwd: given the same arguments (lse filled by the forward, probs ignored) and dO,
+ * writes dQ / dK / dV (each element exactly once - they may be column slices of one fused gradient
+ * buffer) and uses dvec [batch, heads, n_q] as scratch. Broadcast batches are not supported.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t batch, heads, head_dim, n_q, n_k;
@@ -144,10 +210,22 @@ typedef struct {
     const float* mask_add;
     float* O;       int64_t ldo;
     float* probs;
+    float* lse;
     float scale;
+    float dropout_p;
+    uint64_t seed;
 } vb_attention_args;
 
+typedef struct {
+    const float* dO; int64_t lddo;
+    float* dQ;       int64_t lddq;
+    float* dK;       int64_t lddk;
+    float* dV;       int64_t lddv;
+    float* dvec;
+} vb_attention_grads;
+
 int vb_attention_fwd(void* stream, const vb_attention_args* a);
+int vb_attention_bwd(void* stream, const vb_attention_args* a, const vb_attention_grads* g);
 
 #ifdef __cplusplus
 }

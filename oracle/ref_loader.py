@@ -58,7 +58,18 @@ def load():
     pkg = importlib.util.module_from_spec(spec)
     sys.modules[_ALIAS] = pkg
     spec.loader.exec_module(pkg)
-    return importlib.import_module(name)
+    # The reference tries `from apex.normalization.fused_layer_norm import FusedLayerNorm` first
+    # (vilbert.py:297-298). The product ships an `apex` import shim that resolves to the HIP LayerNorm;
+    # the ORACLE must use the reference's own pure-Python BertLayerNorm (:304-317), so apex is made
+    # unimportable while the reference module is executed.
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "apex" or k.startswith("apex.")}
+    sys.modules["apex"] = None
+    try:
+        mod = importlib.import_module(name)
+    finally:
+        del sys.modules["apex"]
+        sys.modules.update(saved)
+    return mod
 
 
 def config_path(name):

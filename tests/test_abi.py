@@ -33,7 +33,8 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = []
+EXTRA_DECLS = ["vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
+               "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd"]
 
 
 def test_library_exports_every_declared_symbol(native):
@@ -48,7 +49,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 1
+    assert lib.vb_abi_version() == 2
     assert lib.vb_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4):
         assert lib.vb_error_string(code).startswith(b"VB_E_")
@@ -57,7 +58,10 @@ def test_abi_version_and_error_strings(native):
 def test_struct_layouts_match_the_header(native):
     # field order / count of the ctypes mirrors against the typedefs in the header
     text = open(HEADER).read()
-    for struct, mirror in (("vb_linear_args", native.LinearArgs), ("vb_attention_args", native.AttentionArgs)):
+    for struct, mirror in (("vb_linear_args", native.LinearArgs), ("vb_attention_args", native.AttentionArgs),
+                           ("vb_attention_grads", native.AttentionGrads),
+                           ("vb_linear_bwd_input_args", native.LinearBwdInputArgs),
+                           ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs)):
         body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", text))[struct]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -75,6 +79,10 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.vb_linear_fwd(None, None) == -1
     assert lib.vb_attention_fwd(None, None) == -1
     assert lib.vb_layernorm_fwd(None, 0, 0, None, None, None, None, 0.0, None, None, None) == -1
+    assert lib.vb_attention_bwd(None, None, None) == -1
+    assert lib.vb_linear_bwd_input(None, None) == -1 and lib.vb_linear_bwd_weight(None, None) == -1
+    assert lib.vb_layernorm_bwd_workspace(64, 768) == 4 * 2 * 768
+    assert lib.vb_layernorm_bwd_workspace(65, 768) == 8 * 2 * 768
 
 
 def test_product_path_has_no_cpu_fallback(native):

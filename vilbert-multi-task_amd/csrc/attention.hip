@@ -1,26 +1,36 @@
-// Fused short-sequence attention, forward:  O = softmax(Q K^T * scale + mask) V  per (sample, head).
+// Fused short-sequence attention:  O = dropout(softmax(Q K^T * scale + mask)) V  per (sample, head),
+// forward and backward.
 //
 // ViLBERT sequences are short (36 tokens / 36 regions pre-training, <= 306 in the task table), so
-// this is not a flash-attention problem: one 64-lane wave owns a 16-query tile of one
-// (sample, head) and keeps the whole score row block in registers - no LDS, no S x S round trip
-// through HBM, no head split / merge copies (Q, K, V are read straight out of the fused
-// [q | k | v] projection, O is written token-major).
+// this is not a flash-attention problem: one 64-lane wave owns a 16-row tile of one (sample, head)
+// and keeps the whole score row block in registers - no LDS, no S x S round trip through HBM, no
+// head split / merge copies (Q, K, V are read straight out of the fused [q | k | v] projection, O is
+// written token-major, the backward writes dQ/dK/dV straight into the fused gradient buffer).
 //
 // MFMA: v_mfma_f32_16x16x4_f32 (exact fp32). Lane l = (c = l & 15, g = l >> 4) supplies
-// A[i = c][k = g] and B[k = g][j = c]; D[row = 4g + r][col = c], r = 0..3.
-//  * scores are computed TRANSPOSED, S^T = K Q^T (A = key rows, B = query rows, contraction over
-//    head_dim with lane group g owning dims 16s + 4g + e): lane (c, g) ends up holding
-//    S[q = c][key = 16 kt + 4g + r] - a fixed query per lane, so the softmax row reduction is
+// A[i = c][k = g] and B[k = g][j = c]; D[row = 4g + r][col = c], r = 0..3. Contractions over
+// head_dim are permuted so that lane group g owns dims 16s + 4g + e (one 16-byte load per 4 MFMAs).
+//
+// forward / backward pass 1 (one wave per 16 queries):
+//  * scores are computed TRANSPOSED, S^T = K Q^T (A = key rows, B = query rows): lane (c, g) holds
+//    S[q = c][key = 16 kt + 4g + r] - a fixed query per lane, so softmax row reductions are
 //    in-register plus two cross-lane steps (xor 16, xor 32);
-//  * that is exactly the A-operand layout of P V (A[i = q = c][k = key], lane group g owning keys
-//    16 kt + 4g + r), so P never leaves its registers; B = V[key][d] is read with plain dword
-//    loads (16 lanes = 64 contiguous bytes).
+//  * that is exactly the A-operand layout of P V (A[i = q][k = key], lane group g owning keys
+//    16 kt + 4g + r), so P never leaves its registers; B = V[key][d] is read with plain dword loads
+//    (16 lanes = 64 contiguous bytes). Pass 1 of the backward reuses the structure for
+//    dP^T = V dO^T, D = rowsum(P dP), dS = P (dP - D) scale and dQ = dS K.
+// backward pass 2 (one wave per 16 keys, looping over query tiles): S = Q K^T with A = query rows,
+//    B = key rows leaves lane (c, g) with S[q = 16 qt + 4g + r][key = c]; P^T and dS^T are then the
+//    A operands of dV = P^T dO and dK = dS^T Q. Softmax statistics come from the saved
+//    log-sum-exp and the D vector written by pass 1. No atomics anywhere.
+// Dropout masks are regenerated from (seed, element index) - see rng.h.
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
 struct AttnP {
-    int batch, heads, n_q, n_k, n_qt;
+    int batch, heads, n_q, n_k, n_qt, n_kt;
     long q_bstride, kv_bstride, m_bstride;  // rows (or mask floats) per sample; 0 = broadcast
     const float* Q; long ldq;
     const float* K; long ldk;
@@ -28,12 +38,48 @@ struct AttnP {
     const float* mask;
     float* O; long ldo;
     float* probs;
+    float* lse;       // [batch, heads, n_q]   forward: out (optional), backward: in
     float scale;
-    long total;  // batch * heads * n_qt wave items
+    float drop_p, drop_scale;
+    uint64_t seed;
+    long total;       // wave items
+    // backward only
+    const float* dO; long lddo;
+    float* dQ; long lddq;
+    float* dK; long lddk;
+    float* dV; long lddv;
+    float* dvec;      // [batch, heads, n_q]  D = rowsum(P dP): pass 1 out, pass 2 in
 };
 
-template <int D, int NT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+template <int DS>
+__device__ __forceinline__ void load_frag(f32x4 (&f)[DS], const float* p) {
+#pragma unroll
+    for (int s = 0; s < DS; ++s) f[s] = *reinterpret_cast<const f32x4*>(p + 16 * s);
+}
+
+template <int DS>
+__device__ __forceinline__ f32x4 dot_tile(const f32x4 (&a)[DS], const f32x4 (&b)[DS]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][e], b[s][e], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// BWD = false: forward.  BWD = true: backward pass 1 (dQ and the D vector).
+template <int D, int NT, bool BWD>
+__global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= p.total) return;
@@ -43,87 +89,125 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     const int b = (int)(bh / p.heads);
     const int c = lane & 15, g = lane >> 4;
     constexpr int DS = D / 16;
-    const int nkt = (p.n_k + 15) >> 4;
+    const int nkt = p.n_kt;
+    const bool drop = p.drop_p > 0.f;
 
-    // Query fragment (B operand of S^T = K Q^T): Q[q = 16 qt + c][16 s + 4 g + e].
+    // Row fragments of this lane's query (B operands): Q[q = 16 qt + c][16 s + 4 g + e], same for dO.
     const int q_row = min(qt * 16 + c, p.n_q - 1);
-    const float* qp = p.Q + ((long)b * p.q_bstride + q_row) * p.ldq + h * D + 4 * g;
     f32x4 qf[DS];
-#pragma unroll
-    for (int s = 0; s < DS; ++s) qf[s] = *reinterpret_cast<const f32x4*>(qp + 16 * s);
+    load_frag<DS>(qf, p.Q + ((long)b * p.q_bstride + q_row) * p.ldq + h * D + 4 * g);
 
-    const float* kbase = p.K + (long)b * p.kv_bstride * p.ldk + h * D + 4 * g;
+    const float* kbase = p.K + (long)b * p.kv_bstride * p.ldk + h * D;
+    const float* vbase = p.V + (long)b * p.kv_bstride * p.ldv + h * D;
     const float* mrow = p.mask != nullptr ? p.mask + (long)b * p.m_bstride : nullptr;
+    const long prow = (bh * p.n_q + q_row) * p.n_k;  // element index of P[b, h, q, 0]
 
     f32x4 st[NT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
+        st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         if (kt < nkt) {
             const int k_row = min(kt * 16 + c, p.n_k - 1);
-            const float* kp = kbase + (long)k_row * p.ldk;
             f32x4 kf[DS];
-#pragma unroll
-            for (int s = 0; s < DS; ++s) kf[s] = *reinterpret_cast<const f32x4*>(kp + 16 * s);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < DS; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s][e], qf[s][e], acc, 0, 0, 0);
+            load_frag<DS>(kf, kbase + (long)k_row * p.ldk + 4 * g);
+            f32x4 acc = dot_tile<DS>(kf, qf);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + 4 * g + r;
                 float v = -INFINITY;
                 if (key < p.n_k) {
-                    // vilbert.py:435-439: scores / sqrt(d) + mask
-                    v = acc[r] * p.scale;
-                    if (mrow != nullptr) v += mrow[key];
+                    // vilbert.py:435-439: scores / sqrt(d) + mask. Two separately rounded steps like
+                    // the reference (no fma contraction): with the -10000 mask one fp32 ulp of the
+                    // sum is 1e-3, so the rounding order shows.
+                    v = __fmul_rn(acc[r], p.scale);
+                    if (mrow != nullptr) v = __fadd_rn(v, mrow[key]);
                 }
                 acc[r] = v;
                 mx = fmaxf(mx, v);
             }
             st[kt] = acc;
-        } else {
-            st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        if (kt < nkt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = expf(st[kt][r] - mx);
-                st[kt][r] = e;
-                sum += e;
-            }
-        }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-        if (kt < nkt) st[kt] *= inv;
-
-    if (p.probs != nullptr && qt * 16 + c < p.n_q) {
-        float* pr = p.probs + (((long)b * p.heads + h) * p.n_q + qt * 16 + c) * p.n_k;
+    if (!BWD) {
+        mx = group_max(mx);
+        float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
             if (kt < nkt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * g + r;
-                    if (key < p.n_k) pr[key] = st[kt][r];
+                    const float e = expf(st[kt][r] - mx);
+                    st[kt][r] = e;
+                    sum += e;
                 }
+        sum = group_sum(sum);
+        const float inv = 1.0f / sum;
+        if (p.lse != nullptr && g == 0 && qt * 16 + c < p.n_q) p.lse[bh * p.n_q + qt * 16 + c] = mx + logf(sum);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = st[kt][r] * inv;
+                    if (drop) {
+                        const int key = kt * 16 + 4 * g + r;
+                        pv = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p) ? pv * p.drop_scale : 0.f;
+                    }
+                    st[kt][r] = pv;
+                }
+        if (p.probs != nullptr && qt * 16 + c < p.n_q) {
+            float* pr = p.probs + prow;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                if (kt < nkt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + 4 * g + r;
+                        if (key < p.n_k) pr[key] = st[kt][r];
+                    }
+        }
+    } else {
+        // P from the saved log-sum-exp, dP^T = V dO^T, D = rowsum(P dP), dS = P (dP - D) scale
+        const float lse = p.lse[bh * p.n_q + q_row];
+        f32x4 dof[DS];
+        load_frag<DS>(dof, p.dO + ((long)b * p.n_q + q_row) * p.lddo + h * D + 4 * g);
+        f32x4 dp[NT];
+        float dsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+                const int k_row = min(kt * 16 + c, p.n_k - 1);
+                f32x4 vf[DS];
+                load_frag<DS>(vf, vbase + (long)k_row * p.ldv + 4 * g);
+                f32x4 acc = dot_tile<DS>(vf, dof);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = min(kt * 16 + 4 * g + r, p.n_k - 1);
+                    const float pv = expf(st[kt][r] - lse);  // exp(-inf) = 0 past n_k
+                    float d = acc[r];
+                    if (drop) d = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p) ? d * p.drop_scale : 0.f;
+                    st[kt][r] = pv;
+                    acc[r] = d;
+                    dsum += pv * d;
+                }
+                dp[kt] = acc;
+            }
+        }
+        dsum = group_sum(dsum);
+        if (g == 0 && qt * 16 + c < p.n_q) p.dvec[bh * p.n_q + qt * 16 + c] = dsum;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * (dp[kt][r] - dsum) * p.scale;
     }
 
-    // O[q][d] = sum_key P[q][key] V[key][d]; one 16-wide d tile per accumulator.
-    const float* vbase = p.V + (long)b * p.kv_bstride * p.ldv + h * D + c;
+    // forward: O[q][d] = sum_key P[q][key] V[key][d];  backward: dQ[q][d] = sum_key dS[q][key] K[key][d]
+    const float* rbase = (BWD ? kbase : vbase) + c;
+    const long ldr = BWD ? p.ldk : p.ldv;
     f32x4 oacc[DS];
 #pragma unroll
     for (int dt = 0; dt < DS; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -132,11 +216,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
         if (kt < nkt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = min(kt * 16 + 4 * g + r, p.n_k - 1);  // P is 0 past n_k
-                const float* vp = vbase + (long)key * p.ldv;
+                const int key = min(kt * 16 + 4 * g + r, p.n_k - 1);  // the A operand is 0 past n_k
+                const float* rp = rbase + (long)key * ldr;
                 float vv[DS];
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) vv[dt] = vp[16 * dt];
+                for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt)
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
@@ -145,53 +229,198 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     }
 
     // D[row = q = 4g + r][col = d = 16 dt + c]
+    float* obase = BWD ? p.dQ : p.O;
+    const long ldo = BWD ? p.lddq : p.ldo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int q = qt * 16 + 4 * g + r;
         if (q < p.n_q) {
-            float* op = p.O + ((long)b * p.n_q + q) * p.ldo + h * D + c;
+            float* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
 #pragma unroll
             for (int dt = 0; dt < DS; ++dt) op[16 * dt] = oacc[dt][r];
         }
     }
 }
 
+// Backward pass 2: one wave per (sample, head, 16-key tile); dK and dV.
 template <int D>
-int launch_attn(hipStream_t st, const AttnP& p) {
-    const int nkt = (p.n_k + 15) / 16;
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= p.total) return;
+    const int kt = (int)(item % p.n_kt);
+    const long bh = item / p.n_kt;
+    const int h = (int)(bh % p.heads);
+    const int b = (int)(bh / p.heads);
+    const int c = lane & 15, g = lane >> 4;
+    constexpr int DS = D / 16;
+    const bool drop = p.drop_p > 0.f;
+
+    const int key = kt * 16 + c;
+    const int k_row = min(key, p.n_k - 1);
+    const bool key_ok = key < p.n_k;
+    f32x4 kf[DS], vf[DS];
+    load_frag<DS>(kf, p.K + ((long)b * p.n_k + k_row) * p.ldk + h * D + 4 * g);
+    load_frag<DS>(vf, p.V + ((long)b * p.n_k + k_row) * p.ldv + h * D + 4 * g);
+    const float madd = p.mask != nullptr ? p.mask[(long)b * p.n_k + k_row] : 0.f;
+
+    const float* qbase = p.Q + (long)b * p.n_q * p.ldq + h * D;
+    const float* dobase = p.dO + (long)b * p.n_q * p.lddo + h * D;
+    const float* lse = p.lse + bh * p.n_q;
+    const float* dvec = p.dvec + bh * p.n_q;
+
+    f32x4 dk[DS], dv[DS];
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt) {
+        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int qt = 0; qt < p.n_qt; ++qt) {
+        const int q_row = min(qt * 16 + c, p.n_q - 1);
+        f32x4 qf[DS], dof[DS];
+        load_frag<DS>(qf, qbase + (long)q_row * p.ldq + 4 * g);
+        load_frag<DS>(dof, dobase + (long)q_row * p.lddo + 4 * g);
+        const f32x4 s = dot_tile<DS>(qf, kf);    // S[q = 16 qt + 4g + r][key = c]
+        const f32x4 dpr = dot_tile<DS>(dof, vf);  // dO V^T, same layout
+        float pd[4], dsv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * g + r;
+            float dsr = 0.f, pdr = 0.f;
+            if (q < p.n_q && key_ok) {
+                const float sv = __fadd_rn(__fmul_rn(s[r], p.scale), madd);
+                const float pv = expf(sv - lse[q]);
+                float d = dpr[r];
+                pdr = pv;
+                if (drop) {
+                    const bool keep = vb_keep(p.seed, (uint64_t)((bh * p.n_q + q) * p.n_k + key), p.drop_p);
+                    d = keep ? d * p.drop_scale : 0.f;
+                    pdr = keep ? pv * p.drop_scale : 0.f;
+                }
+                dsr = pv * (d - dvec[q]) * p.scale;
+            }
+            pd[r] = pdr;
+            dsv[r] = dsr;
+        }
+        // dV[key][d] += sum_q Pdrop[q][key] dO[q][d];  dK[key][d] += sum_q dS[q][key] Q[q][d]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = min(qt * 16 + 4 * g + r, p.n_q - 1);  // A operands are 0 past n_q
+            const float* dop = dobase + (long)q * p.lddo + c;
+            const float* qp = qbase + (long)q * p.ldq + c;
+            float dov[DS], qv[DS];
+#pragma unroll
+            for (int dt = 0; dt < DS; ++dt) {
+                dov[dt] = dop[16 * dt];
+                qv[dt] = qp[16 * dt];
+            }
+#pragma unroll
+            for (int dt = 0; dt < DS; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[r], dov[dt], dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[r], qv[dt], dk[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // D[row = key = 4g + r][col = d = 16 dt + c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kk = kt * 16 + 4 * g + r;
+        if (kk < p.n_k) {
+            float* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
+            float* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
+#pragma unroll
+            for (int dt = 0; dt < DS; ++dt) {
+                kp[16 * dt] = dk[dt][r];
+                vp[16 * dt] = dv[dt][r];
+            }
+        }
+    }
+}
+
+template <int D, bool BWD>
+int launch_q(hipStream_t st, const AttnP& p) {
     dim3 block(256), grid((unsigned)((p.total + 3) / 4));
-    if (nkt <= 3) hipLaunchKernelGGL((attn_fwd_kernel<D, 3>), grid, block, 0, st, p);
-    else if (nkt <= 8) hipLaunchKernelGGL((attn_fwd_kernel<D, 8>), grid, block, 0, st, p);
-    else if (nkt <= 20) hipLaunchKernelGGL((attn_fwd_kernel<D, 20>), grid, block, 0, st, p);
+    if (p.n_kt <= 3) hipLaunchKernelGGL((attn_q_kernel<D, 3, BWD>), grid, block, 0, st, p);
+    else if (p.n_kt <= 8) hipLaunchKernelGGL((attn_q_kernel<D, 8, BWD>), grid, block, 0, st, p);
+    else if (p.n_kt <= 20) hipLaunchKernelGGL((attn_q_kernel<D, 20, BWD>), grid, block, 0, st, p);
     else return VB_E_RANGE;
     VB_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D>
+int launch_kv(hipStream_t st, const AttnP& p) {
+    dim3 block(256), grid((unsigned)((p.total + 3) / 4));
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<D>), grid, block, 0, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+int fill_common(AttnP& p, const vb_attention_args* a) {
+    if (a == nullptr || a->Q == nullptr || a->K == nullptr || a->V == nullptr) return VB_E_BADARG;
+    if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_k <= 0) return VB_E_BADARG;
+    if (a->n_k > VB_MAX_KEYS) return VB_E_RANGE;
+    if ((a->q_batch != a->batch && a->q_batch != 1) || (a->kv_batch != a->batch && a->kv_batch != 1))
+        return VB_E_BADARG;
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
+    if ((a->ldq | a->ldk | a->ldv) % 4 != 0 || !vb_aligned16(a->Q) || !vb_aligned16(a->K) || !vb_aligned16(a->V))
+        return VB_E_ALIGN;
+    p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_k = a->n_k;
+    p.n_qt = (a->n_q + 15) / 16;
+    p.n_kt = (a->n_k + 15) / 16;
+    p.q_bstride = a->q_batch == 1 && a->batch > 1 ? 0 : a->n_q;
+    p.kv_bstride = a->kv_batch == 1 && a->batch > 1 ? 0 : a->n_k;
+    p.m_bstride = p.kv_bstride;
+    p.Q = a->Q; p.ldq = a->ldq; p.K = a->K; p.ldk = a->ldk; p.V = a->V; p.ldv = a->ldv;
+    p.mask = a->mask_add; p.scale = a->scale; p.lse = a->lse;
+    p.drop_p = a->dropout_p; p.drop_scale = 1.0f / (1.0f - a->dropout_p); p.seed = a->seed;
     return 0;
 }
 
 }  // namespace
 
 extern "C" int vb_attention_fwd(void* stream, const vb_attention_args* a) {
-    if (a == nullptr || a->Q == nullptr || a->K == nullptr || a->V == nullptr || a->O == nullptr)
-        return VB_E_BADARG;
-    if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_k <= 0) return VB_E_BADARG;
-    if (a->n_k > VB_MAX_KEYS) return VB_E_RANGE;
-    if ((a->q_batch != a->batch && a->q_batch != 1) || (a->kv_batch != a->batch && a->kv_batch != 1))
-        return VB_E_BADARG;
-    if ((a->ldq | a->ldk) % 4 != 0 || !vb_aligned16(a->Q) || !vb_aligned16(a->K)) return VB_E_ALIGN;
     AttnP p{};
-    p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_k = a->n_k;
-    p.n_qt = (a->n_q + 15) / 16;
-    p.q_bstride = a->q_batch == 1 && a->batch > 1 ? 0 : a->n_q;
-    p.kv_bstride = a->kv_batch == 1 && a->batch > 1 ? 0 : a->n_k;
-    p.m_bstride = p.kv_bstride;
-    p.Q = a->Q; p.ldq = a->ldq; p.K = a->K; p.ldk = a->ldk; p.V = a->V; p.ldv = a->ldv;
-    p.mask = a->mask_add; p.O = a->O; p.ldo = a->ldo; p.probs = a->probs; p.scale = a->scale;
+    if (int e = fill_common(p, a)) return e;
+    if (a->O == nullptr) return VB_E_BADARG;
+    p.O = a->O; p.ldo = a->ldo; p.probs = a->probs;
     p.total = (long)a->batch * a->heads * p.n_qt;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (a->head_dim) {
-        case 32: return launch_attn<32>(st, p);
-        case 64: return launch_attn<64>(st, p);
-        case 128: return launch_attn<128>(st, p);
+        case 32: return launch_q<32, false>(st, p);
+        case 64: return launch_q<64, false>(st, p);
+        case 128: return launch_q<128, false>(st, p);
         default: return VB_E_RANGE;
+    }
+}
+
+extern "C" int vb_attention_bwd(void* stream, const vb_attention_args* a, const vb_attention_grads* gr) {
+    AttnP p{};
+    if (int e = fill_common(p, a)) return e;
+    if (gr == nullptr || gr->dO == nullptr || gr->dQ == nullptr || gr->dK == nullptr || gr->dV == nullptr ||
+        gr->dvec == nullptr || a->lse == nullptr)
+        return VB_E_BADARG;
+    if (a->q_batch != a->batch || a->kv_batch != a->batch) return VB_E_BADARG;  // no broadcast in training
+    if (gr->lddo % 4 != 0 || !vb_aligned16(gr->dO)) return VB_E_ALIGN;
+    p.dO = gr->dO; p.lddo = gr->lddo;
+    p.dQ = gr->dQ; p.lddq = gr->lddq; p.dK = gr->dK; p.lddk = gr->lddk; p.dV = gr->dV; p.lddv = gr->lddv;
+    p.dvec = gr->dvec;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int e = 0;
+    p.total = (long)a->batch * a->heads * p.n_qt;
+    switch (a->head_dim) {
+        case 32: e = launch_q<32, true>(st, p); break;
+        case 64: e = launch_q<64, true>(st, p); break;
+        case 128: e = launch_q<128, true>(st, p); break;
+        default: return VB_E_RANGE;
+    }
+    if (e) return e;
+    p.total = (long)a->batch * a->heads * p.n_kt;
+    switch (a->head_dim) {
+        case 32: return launch_kv<32>(st, p);
+        case 64: return launch_kv<64>(st, p);
+        default: return launch_kv<128>(st, p);
     }
 }

@@ -1,0 +1,82 @@
+// Elementwise kernels of the training path (HBM-bound, 16-byte accesses, grid-stride):
+//   activation backward  dpre = dy * act'(pre)
+//   dropout              y = x * keep(seed, i) / (1 - p)   (the same launch serves forward and backward)
+#include "common.h"
+#include "rng.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_grad(float x) {
+    // d/dx [x * 0.5 * (1 + erf(x / sqrt 2))] = 0.5 (1 + erf(x / sqrt 2)) + x * exp(-x^2 / 2) / sqrt(2 pi)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(long n4, const f32x4* __restrict__ dy,
+                                                      const f32x4* __restrict__ pre, f32x4* __restrict__ dx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 g = dy[i], x = pre[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ACT == VB_ACT_GELU ? g[e] * gelu_grad(x[e]) : (x[e] > 0.f ? g[e] : 0.f);
+        dx[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(long n, const float* __restrict__ x,
+                                                      const float* __restrict__ res, float* __restrict__ y,
+                                                      float p, float scale, uint64_t seed) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 o = res != nullptr ? reinterpret_cast<const f32x4*>(res)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (vb_keep(seed, (uint64_t)(4 * i + e), p)) o[e] += v[e] * scale;
+        reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        y[i] = (res != nullptr ? res[i] : 0.f) + (vb_keep(seed, (uint64_t)i, p) ? x[i] * scale : 0.f);
+    }
+}
+
+inline unsigned grid_for(long work_items) {
+    long blocks = (work_items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;  // ~8 blocks per CU, grid-stride the rest
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int vb_act_bwd(void* stream, int64_t n, int32_t act, const float* dy, const float* preact, float* dx) {
+    if (dy == nullptr || preact == nullptr || dx == nullptr || n <= 0) return VB_E_BADARG;
+    if (n % 4 != 0 || !vb_aligned16(dy) || !vb_aligned16(preact) || !vb_aligned16(dx)) return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long n4 = n / 4;
+    if (act == VB_ACT_GELU)
+        hipLaunchKernelGGL(act_bwd_kernel<VB_ACT_GELU>, dim3(grid_for(n4)), dim3(256), 0, st, n4,
+                           reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(preact),
+                           reinterpret_cast<f32x4*>(dx));
+    else if (act == VB_ACT_RELU)
+        hipLaunchKernelGGL(act_bwd_kernel<VB_ACT_RELU>, dim3(grid_for(n4)), dim3(256), 0, st, n4,
+                           reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(preact),
+                           reinterpret_cast<f32x4*>(dx));
+    else
+        return VB_E_BADARG;
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_dropout(void* stream, int64_t n, const float* x, const float* residual, float* y, float p,
+                          uint64_t seed) {
+    if (x == nullptr || y == nullptr || n <= 0 || !(p >= 0.f && p < 1.f)) return VB_E_BADARG;
+    if (!vb_aligned16(x) || !vb_aligned16(y) || (residual != nullptr && !vb_aligned16(residual))) return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, (long)n, x, residual, y, p,
+                       1.0f / (1.0f - p), seed);
+    VB_LAUNCH_CHECK();
+    return 0;
+}

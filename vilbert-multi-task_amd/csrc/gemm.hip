@@ -46,40 +46,50 @@ struct GemmP {
     int accumulate;       // C += result
     int tiles_m, tiles_n;
     int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
+    float* colsum;        // row-contiguous A only: colsum[i] += sum_k A[i][k] (bias gradient), may be null
 };
 
-// Stage one 128 x 32 operand tile into registers (4 float4 per thread).
-// KC: global [rows][ld] with k contiguous.  RC: global [k][ld] with rows contiguous.
-template <bool KC, bool VEC>
-__device__ __forceinline__ void load_tile(f32x4 (&reg)[4], const float* __restrict__ base, long ld,
-                                          int row0, int nrows, int k0, int K, int tid) {
+// Staging of one 128 x 32 operand tile into registers (4 float4 per thread).
+// k-contiguous operand (global [rows][ld]): thread t owns rows (t >> 3) + 32 it, it = 0..3, and the
+// four k values 4 (t & 7) .. +3 of every K tile, so the row base pointers are computed once per
+// block (this is also where a row is mapped to its weight segment).
+template <bool VEC>
+__device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[4], const float* const (&rowp)[4], int k, int K) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rowp[it] != nullptr) {
+            const float* g = rowp[it] + k;
+            if (VEC) {
+                if (k < K) v = *reinterpret_cast<const f32x4*>(g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < K) v[e] = g[e];
+            }
+        }
+        reg[it] = v;
+    }
+}
+
+// row-contiguous operand (global [k][ld], rows contiguous): thread t owns k = (t >> 5) + 8 it and the
+// four rows row0 + 4 (t & 31) .. +3.
+template <bool VEC>
+__device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[4], const float* __restrict__ base, long ld,
+                                             int row0, int nrows, int k0, int K, int tid) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int f = tid + 256 * it;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (KC) {
-            const int row = row0 + (f >> 3), k = k0 + (f & 7) * 4;
-            if (row < nrows) {
-                const float* g = base + (long)row * ld + k;
-                if (VEC) {
-                    if (k < K) v = *reinterpret_cast<const f32x4*>(g);
-                } else {
+        const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
+        if (k < K) {
+            const float* g = base + (long)k * ld + row;
+            if (VEC) {
+                if (row < nrows) v = *reinterpret_cast<const f32x4*>(g);
+            } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (k + e < K) v[e] = g[e];
-                }
-            }
-        } else {
-            const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
-            if (k < K) {
-                const float* g = base + (long)k * ld + row;
-                if (VEC) {
-                    if (row < nrows) v = *reinterpret_cast<const f32x4*>(g);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (row + e < nrows) v[e] = g[e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (row + e < nrows) v[e] = g[e];
             }
         }
         reg[it] = v;
@@ -119,14 +129,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     const int kt_end = min(kt_total, kt_begin + p.ktiles_per_split);
     if (kt_begin >= kt_end) return;
 
-    // B segment: along N for a k-contiguous B (weights stacked along out features), along K for
-    // a row-contiguous B (dgrad through stacked weights).
-    const float* Bbase = p.B[0];
-    int b_row_off = 0;
-    if (B_KC) {
-        const int s = n0 / p.bseg;
-        Bbase = p.B[s];
-        b_row_off = s * p.bseg;
+    // Row base pointers of the k-contiguous operands. B rows (= output columns) are mapped to their
+    // weight segment here: the segments are stacked along N (q | k | v projections in one launch).
+    const float* arow[4] = {nullptr, nullptr, nullptr, nullptr};
+    const float* brow[4] = {nullptr, nullptr, nullptr, nullptr};
+    const int kq = (tid & 7) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 3) + 32 * it;
+        if (A_KC && m0 + r < p.M) arow[it] = p.A + (long)(m0 + r) * p.lda;
+        if (B_KC && n0 + r < p.N) {
+            const int n = n0 + r, sg = n / p.bseg;
+            brow[it] = p.B[sg] + (long)(n - sg * p.bseg) * p.ldb;
+        }
     }
 
     f32x16 acc[2][2];
@@ -138,16 +153,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[4], rb[4];
+    float csum = 0.f;
 
     auto load_ab = [&](int kt) {
         const int k0 = kt * BK;
-        load_tile<A_KC, VEC>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
+        if (A_KC) load_tile_kc<VEC>(ra, arow, k0 + kq, p.K);
+        else load_tile_rc<VEC>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
         if (B_KC) {
-            load_tile<true, VEC>(rb, Bbase, p.ldb, n0 - b_row_off, p.bseg, k0, p.K, tid);
+            load_tile_kc<VEC>(rb, brow, k0 + kq, p.K);
         } else {
-            const int s = k0 / p.bseg;
-            load_tile<false, VEC>(rb, p.B[s], p.ldb, n0, p.N, k0 - s * p.bseg,
-                                  min(p.bseg, p.K - s * p.bseg), tid);
+            // segments stacked along K (dgrad through stacked weights); bseg is a multiple of BK
+            const int sg = k0 / p.bseg;
+            load_tile_rc<VEC>(rb, p.B[sg], p.ldb, n0, p.N, k0 - sg * p.bseg, min(p.bseg, p.K - sg * p.bseg), tid);
         }
     };
 
@@ -195,6 +212,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
                                                                         acc[i][j], 0, 0, 0);
         }
 
+        if (!A_KC && p.colsum != nullptr && n0 == 0 && tid < BM) {
+            // bias gradient fused into wgrad: A = dY^T, so the sum over this K tile of row i = tid
+#pragma unroll
+            for (int kk = 0; kk < BK; ++kk) csum += sA[kk * RC_LD + tid];
+        }
+
         if (more) {
             float* dA = smem + (cur ^ 1) * STAGE_SZ;
             store_tile<A_KC>(dA, ra, tid);
@@ -202,6 +225,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         }
         __syncthreads();
     }
+
+    if (!A_KC && p.colsum != nullptr && n0 == 0 && tid < BM && m0 + tid < p.M)
+        unsafeAtomicAdd(p.colsum + m0 + tid, csum);
 
     // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     const bool split = gridDim.y > 1;
@@ -261,7 +287,6 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     if (a == nullptr || a->A == nullptr || a->C == nullptr) return VB_E_BADARG;
     if (a->M <= 0 || a->K <= 0 || a->seg_n <= 0) return VB_E_BADARG;
     if (a->nseg < 1 || a->nseg > VB_MAX_SEGMENTS) return VB_E_SEGMENT;
-    if (a->nseg > 1 && (a->seg_n % BN) != 0) return VB_E_SEGMENT;
     if (a->act < VB_ACT_NONE || a->act > VB_ACT_RELU) return VB_E_BADARG;
     GemmP p{};
     p.M = a->M; p.K = a->K; p.N = a->nseg * a->seg_n;
@@ -282,4 +307,74 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     p.tiles_n = (p.N + BN - 1) / BN;
     p.ktiles_per_split = (p.K + BK - 1) / BK;
     return launch_gemm<true, true>(static_cast<hipStream_t>(stream), p, vec, 1);
+}
+
+// dX[M,K] (+)= dY[M, nseg*seg_n] . stack(W)   - nn.Linear backward w.r.t. its input
+extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args* a) {
+    if (a == nullptr || a->dY == nullptr || a->dX == nullptr) return VB_E_BADARG;
+    if (a->M <= 0 || a->K <= 0 || a->seg_n <= 0) return VB_E_BADARG;
+    if (a->nseg < 1 || a->nseg > VB_MAX_SEGMENTS) return VB_E_SEGMENT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // a K tile of the contraction (over out-features) must not straddle two weight segments; otherwise
+    // run one launch per segment, accumulating.
+    const bool fused = a->nseg == 1 || (a->seg_n % BK) == 0;
+    const int launches = fused ? 1 : a->nseg;
+    for (int l = 0; l < launches; ++l) {
+        GemmP p{};
+        p.M = a->M; p.N = a->K;  // output is [M, in_features]
+        p.K = fused ? a->nseg * a->seg_n : a->seg_n;
+        p.A = a->dY + (fused ? 0 : (long)l * a->seg_n); p.lda = a->ldy;
+        p.ldb = a->ldw; p.bseg = a->seg_n;
+        bool vec = (a->K % 4 == 0) && (a->seg_n % 4 == 0) && (a->ldy % 4 == 0) && (a->ldw % 4 == 0) &&
+                   vb_aligned16(p.A);
+        for (int s = 0; s < (fused ? a->nseg : 1); ++s) {
+            const float* w = a->W[fused ? s : l];
+            if (w == nullptr) return VB_E_SEGMENT;
+            p.B[s] = w;
+            vec = vec && vb_aligned16(w);
+        }
+        p.C = a->dX; p.ldc = a->ldx;
+        p.act = VB_ACT_NONE;
+        p.accumulate = (a->accumulate || l > 0) ? 1 : 0;
+        p.tiles_m = (p.M + BM - 1) / BM;
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.ktiles_per_split = (p.K + BK - 1) / BK;
+        if (int e = launch_gemm<true, false>(st, p, vec, 1)) return e;
+    }
+    return 0;
+}
+
+// dW[n,K] (+)= dY[:, :n]^T . X[M,K] and dbias[n] (+)= column sums of dY   - nn.Linear backward w.r.t.
+// weight and bias. The contraction runs over the M rows: split over gridDim.y with fp32 atomics.
+extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_args* a) {
+    if (a == nullptr || a->dY == nullptr || a->X == nullptr || a->dW == nullptr) return VB_E_BADARG;
+    if (a->M <= 0 || a->K <= 0 || a->n <= 0) return VB_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!a->accumulate) {
+        hipError_t e = hipMemset2DAsync(a->dW, a->ldw * sizeof(float), 0, (size_t)a->K * sizeof(float), a->n, st);
+        if (e != hipSuccess) return (int)e;
+        if (a->dbias != nullptr) {
+            e = hipMemsetAsync(a->dbias, 0, (size_t)a->n * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    GemmP p{};
+    p.M = a->n; p.N = a->K; p.K = a->M;
+    p.A = a->dY; p.lda = a->ldy;
+    p.B[0] = a->X; p.ldb = a->ldx; p.bseg = a->M;
+    p.C = a->dW; p.ldc = a->ldw;
+    p.act = VB_ACT_NONE; p.accumulate = 1;
+    p.colsum = a->dbias;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int kt_total = (p.K + BK - 1) / BK;
+    const int tiles = p.tiles_m * p.tiles_n;
+    int splits = (1024 + tiles - 1) / tiles;  // aim at ~4 blocks per CU
+    if (splits > kt_total) splits = kt_total;
+    if (splits < 1) splits = 1;
+    p.ktiles_per_split = (kt_total + splits - 1) / splits;
+    splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
+    const bool vec = (a->n % 4 == 0) && (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) &&
+                     vb_aligned16(a->dY) && vb_aligned16(a->X);
+    return launch_gemm<false, false>(st, p, vec, splits);
 }

@@ -16,7 +16,14 @@ constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
 template <int NV>
 __device__ __forceinline__ void ln_finish(f32x4 (&x)[NV], int n_cols, int lane, const float* gamma,
                                           const float* beta, float eps, float* yrow, float* mean_out,
-                                          float* rstd_out) {
+                                          float* rstd_out, float* presum_row = nullptr) {
+    if (presum_row != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            if (col < n_cols) *reinterpret_cast<f32x4*>(presum_row + col) = x[i];
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -86,7 +93,8 @@ __global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, i
                                                          const float* __restrict__ task_emb,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
-                                                         float* __restrict__ out, float* mean, float* rstd) {
+                                                         float* __restrict__ out, float* mean, float* rstd,
+                                                         float* presum) {
     const int lane = threadIdx.x & 63;
     const int n_out = n_tok + (task_ids != nullptr ? 1 : 0);
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, i
         }
     }
     ln_finish<NV>(v, hidden, lane, gamma, beta, eps, out + row * hidden, mean ? mean + row : nullptr,
-                  rstd ? rstd + row : nullptr);
+                  rstd ? rstd + row : nullptr, presum ? presum + row * hidden : nullptr);
 }
 
 // reference vilbert.py:1421-1432 (the 5 -> hidden location projection, the sum and the LayerNorm)
@@ -130,7 +138,8 @@ __global__ __launch_bounds__(256) void image_embed_kernel(long rows, int hidden,
                                                           const float* __restrict__ b_loc,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ out, float* mean, float* rstd) {
+                                                          float* __restrict__ out, float* mean, float* rstd,
+                                                          float* presum) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void image_embed_kernel(long rows, int hidden,
         }
     }
     ln_finish<NV>(v, hidden, lane, gamma, beta, eps, out + row * hidden, mean ? mean + row : nullptr,
-                  rstd ? rstd + row : nullptr);
+                  rstd ? rstd + row : nullptr, presum ? presum + row * hidden : nullptr);
 }
 
 template <typename T>
@@ -209,7 +218,8 @@ extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, 
                                     const int64_t* ids, const int64_t* seg, int32_t pos_offset,
                                     const float* word_emb, const float* pos_emb, const float* type_emb,
                                     const int64_t* task_ids, const float* task_emb, const float* gamma,
-                                    const float* beta, float eps, float* out, float* mean, float* rstd) {
+                                    const float* beta, float eps, float* out, float* mean, float* rstd,
+                                    float* presum) {
     if (ids == nullptr || seg == nullptr || word_emb == nullptr || pos_emb == nullptr || type_emb == nullptr ||
         gamma == nullptr || beta == nullptr || out == nullptr || batch <= 0 || n_tok <= 0)
         return VB_E_BADARG;
@@ -224,7 +234,7 @@ extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, 
     VB_NV_DISPATCH(nv_for(hidden),
                    hipLaunchKernelGGL((text_embed_kernel<NV>), grid, block, 0, st, batch, n_tok, hidden, ids, seg,
                                       pos_offset, word_emb, pos_emb, type_emb, task_ids, task_emb, gamma, beta,
-                                      eps, out, mean, rstd));
+                                      eps, out, mean, rstd, presum));
     VB_LAUNCH_CHECK();
     return 0;
 }
@@ -232,7 +242,7 @@ extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, 
 extern "C" int vb_image_embed_ln_fwd(void* stream, int64_t rows, int32_t hidden, const float* feat_proj,
                                      const float* loc, const float* w_loc, const float* b_loc,
                                      const float* gamma, const float* beta, float eps, float* out, float* mean,
-                                     float* rstd) {
+                                     float* rstd, float* presum) {
     if (feat_proj == nullptr || loc == nullptr || w_loc == nullptr || b_loc == nullptr || gamma == nullptr ||
         beta == nullptr || out == nullptr || rows <= 0)
         return VB_E_BADARG;
@@ -244,7 +254,7 @@ extern "C" int vb_image_embed_ln_fwd(void* stream, int64_t rows, int32_t hidden,
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
     VB_NV_DISPATCH(nv_for(hidden),
                    hipLaunchKernelGGL((image_embed_kernel<NV>), grid, block, 0, st, (long)rows, hidden, feat_proj,
-                                      loc, w_loc, b_loc, gamma, beta, eps, out, mean, rstd));
+                                      loc, w_loc, b_loc, gamma, beta, eps, out, mean, rstd, presum));
     VB_LAUNCH_CHECK();
     return 0;
 }
@@ -259,6 +269,190 @@ extern "C" int vb_additive_mask(void* stream, int64_t n, const void* mask, int32
     else
         hipLaunchKernelGGL(additive_mask_kernel<int64_t>, grid, block, 0, st, (long)n,
                            static_cast<const int64_t*>(mask), out);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward. Per row (xhat = (x - mean) rstd, g = dy * gamma):
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+//   dgamma = sum_rows dy * xhat,  dbeta = sum_rows dy
+// Stage 1: one wave walks LNB_ROWS_PER_WAVE rows keeping its column partials of dgamma / dbeta in
+// registers and writes them to a workspace row; stage 2 sums the workspace rows column-wise. No
+// atomics: the result is deterministic.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int LNB_ROWS_PER_WAVE = 16;
+constexpr int LNB_ROWS_PER_BLOCK = 4 * LNB_ROWS_PER_WAVE;
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int n_cols, const float* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ dx, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long part = (long)blockIdx.x * 4 + wave;
+    const long row_begin = part * LNB_ROWS_PER_WAVE;
+    f32x4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        gam[i] = col < n_cols ? *reinterpret_cast<const f32x4*>(gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int rr = 0; rr < LNB_ROWS_PER_WAVE; ++rr) {
+        const long row = row_begin + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col < n_cols) {
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * n_cols + col);
+                xh[i] = (*reinterpret_cast<const f32x4*>(x + row * n_cols + col) - mu) * rs;
+                g[i] = d * gam[i];
+                dg[i] += d * xh[i];
+                db[i] += d;
+                s1 += (g[i][0] + g[i][1]) + (g[i][2] + g[i][3]);
+                s2 += (g[i][0] * xh[i][0] + g[i][1] * xh[i][1]) + (g[i][2] * xh[i][2] + g[i][3] * xh[i][3]);
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)n_cols, m2 = wave_sum(s2) / (float)n_cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            if (col < n_cols)
+                *reinterpret_cast<f32x4*>(dx + row * n_cols + col) = (g[i] - m1 - xh[i] * m2) * rs;
+        }
+    }
+    float* w = ws + part * 2 * n_cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < n_cols) {
+            *reinterpret_cast<f32x4*>(w + col) = dg[i];
+            *reinterpret_cast<f32x4*>(w + n_cols + col) = db[i];
+        }
+    }
+}
+
+// Column sums of `parts` workspace rows of width 2 * n_cols. Block = 1024 threads = 16 row groups x
+// 64 columns; each group strides over the parts, then an LDS tree over the 16 groups.
+__global__ __launch_bounds__(1024) void colreduce_kernel(long parts, int width, const float* __restrict__ ws,
+                                                         float* __restrict__ out0, float* __restrict__ out1,
+                                                         int n_cols) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float acc = 0.f;
+    if (col < width)
+        for (long r = pg; r < parts; r += 16) acc += ws[r * width + col];
+    red[pg][c] = acc;
+    __syncthreads();
+    if (pg == 0 && col < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        if (col < n_cols) out0[col] = t;
+        else out1[col - n_cols] = t;
+    }
+}
+
+// Scatter-add of embedding-row gradients (fp32 atomics into the zero-filled tables).
+// reference vilbert.py:353-362 backward; word row 0 is padding_idx (no gradient from the gather).
+template <int NV>
+__global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int n_tok, int hidden,
+                                                                 const int64_t* __restrict__ ids,
+                                                                 const int64_t* __restrict__ seg,
+                                                                 const int64_t* __restrict__ task_ids,
+                                                                 const float* __restrict__ dx,
+                                                                 float* __restrict__ dword, float* __restrict__ dpos,
+                                                                 float* __restrict__ dtype, float* __restrict__ dtask) {
+    const int lane = threadIdx.x & 63;
+    const int n_out = n_tok + (task_ids != nullptr ? 1 : 0);
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= (long)batch * n_out) return;
+    const int b = (int)(row / n_out), t_out = (int)(row % n_out);
+    const bool is_task = task_ids != nullptr && t_out == 1;
+    const int t = (task_ids != nullptr && t_out >= 2) ? t_out - 1 : t_out;
+    float *w = nullptr, *pp = nullptr, *ty = nullptr;
+    if (is_task) {
+        w = dtask + task_ids[b] * hidden;
+    } else {
+        const int64_t id = ids[(long)b * n_tok + t];
+        w = id != 0 ? dword + id * hidden : nullptr;
+        pp = dpos + (long)t * hidden;
+        ty = dtype + seg[(long)b * n_tok + t] * hidden;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < hidden) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dx + row * hidden + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (w != nullptr) unsafeAtomicAdd(w + col + e, d[e]);
+                if (pp != nullptr) unsafeAtomicAdd(pp + col + e, d[e]);
+                if (ty != nullptr) unsafeAtomicAdd(ty + col + e, d[e]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t vb_layernorm_bwd_workspace(int64_t rows, int32_t n_cols) {
+    if (rows <= 0 || n_cols <= 0) return 0;
+    const int64_t parts = (rows + LNB_ROWS_PER_WAVE - 1) / LNB_ROWS_PER_WAVE;
+    const int64_t parts_padded = (parts + 3) / 4 * 4;  // whole blocks write
+    return parts_padded * 2 * n_cols;
+}
+
+extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
+                                const float* mean, const float* rstd, const float* gamma, float* dx,
+                                float* dgamma, float* dbeta, float* workspace) {
+    if (dy == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || gamma == nullptr || dx == nullptr ||
+        dgamma == nullptr || dbeta == nullptr || workspace == nullptr || rows <= 0)
+        return VB_E_BADARG;
+    if (int e = check_cols(n_cols)) return e;
+    if (!vb_aligned16(dy) || !vb_aligned16(x) || !vb_aligned16(dx) || !vb_aligned16(gamma) || !vb_aligned16(workspace))
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long blocks = (rows + LNB_ROWS_PER_BLOCK - 1) / LNB_ROWS_PER_BLOCK;
+    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256),
+                                                      0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx,
+                                                      workspace));
+    VB_LAUNCH_CHECK();
+    const int width = 2 * n_cols;
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, blocks * 4, width,
+                       workspace, dgamma, dbeta, n_cols);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, const int64_t* ids,
+                                 const int64_t* seg, const int64_t* task_ids, const float* dx, float* dword,
+                                 float* dpos, float* dtype, float* dtask) {
+    if (ids == nullptr || seg == nullptr || dx == nullptr || dword == nullptr || dpos == nullptr ||
+        dtype == nullptr || batch <= 0 || n_tok <= 0)
+        return VB_E_BADARG;
+    if (task_ids != nullptr && dtask == nullptr) return VB_E_BADARG;
+    if (int e = check_cols(hidden)) return e;
+    if (!vb_aligned16(dx)) return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long rows = (long)batch * (n_tok + (task_ids != nullptr ? 1 : 0));
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(hidden), hipLaunchKernelGGL((text_embed_scatter_kernel<NV>), grid, block, 0, st, batch,
+                                                      n_tok, hidden, ids, seg, task_ids, dx, dword, dpos, dtype,
+                                                      dtask));
     VB_LAUNCH_CHECK();
     return 0;
 }

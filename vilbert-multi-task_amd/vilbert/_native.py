@@ -46,23 +46,69 @@ class AttentionArgs(ctypes.Structure):
         ("mask_add", _c_f32p),
         ("O", _c_f32p), ("ldo", ctypes.c_int64),
         ("probs", _c_f32p),
+        ("lse", _c_f32p),
         ("scale", ctypes.c_float),
+        ("dropout_p", ctypes.c_float),
+        ("seed", ctypes.c_uint64),
+    ]
+
+
+class AttentionGrads(ctypes.Structure):
+    """vb_attention_grads"""
+    _fields_ = [
+        ("dO", _c_f32p), ("lddo", ctypes.c_int64),
+        ("dQ", _c_f32p), ("lddq", ctypes.c_int64),
+        ("dK", _c_f32p), ("lddk", ctypes.c_int64),
+        ("dV", _c_f32p), ("lddv", ctypes.c_int64),
+        ("dvec", _c_f32p),
+    ]
+
+
+class LinearBwdInputArgs(ctypes.Structure):
+    """vb_linear_bwd_input_args"""
+    _fields_ = [
+        ("M", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32),
+        ("dY", _c_f32p), ("ldy", ctypes.c_int64),
+        ("W", _c_f32p * VB_MAX_SEGMENTS), ("ldw", ctypes.c_int64),
+        ("dX", _c_f32p), ("ldx", ctypes.c_int64),
+        ("accumulate", ctypes.c_int32),
+    ]
+
+
+class LinearBwdWeightArgs(ctypes.Structure):
+    """vb_linear_bwd_weight_args"""
+    _fields_ = [
+        ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("n", ctypes.c_int32),
+        ("dY", _c_f32p), ("ldy", ctypes.c_int64),
+        ("X", _c_f32p), ("ldx", ctypes.c_int64),
+        ("dW", _c_f32p), ("ldw", ctypes.c_int64),
+        ("dbias", _c_f32p),
+        ("accumulate", ctypes.c_int32),
     ]
 
 
 # name -> (restype, argtypes); mirrors include/vilbert_hip.h one to one (checked by
 # tests/test_abi.py against the header text).
-_I32, _I64, _F32, _P = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+_I32, _I64, _F32, _P, _U64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64
 SIGNATURES = {
     "vb_abi_version": (ctypes.c_int, []),
     "vb_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
+    "vb_linear_bwd_input": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdInputArgs)]),
+    "vb_linear_bwd_weight": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdWeightArgs)]),
+    "vb_act_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
+    "vb_dropout": (ctypes.c_int, [_P, _I64, _P, _P, _P, _F32, _U64]),
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
+    "vb_layernorm_bwd_workspace": (ctypes.c_int64, [_I64, _I32]),
+    "vb_layernorm_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vb_text_embed_ln_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
-                                             _F32, _P, _P, _P]),
-    "vb_image_embed_ln_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _F32, _P, _P, _P]),
+                                             _F32, _P, _P, _P, _P]),
+    "vb_text_embed_bwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vb_image_embed_ln_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _F32, _P, _P, _P, _P]),
     "vb_additive_mask": (ctypes.c_int, [_P, _I64, _P, _I32, _P]),
     "vb_attention_fwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs)]),
+    "vb_attention_bwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs), ctypes.POINTER(AttentionGrads)]),
 }
 
 _lib = None
@@ -80,7 +126,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 1:
+        if handle.vb_abi_version() != 2:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib

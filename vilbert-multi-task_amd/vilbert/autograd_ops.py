@@ -1,0 +1,189 @@
+"""``torch.autograd.Function`` wrappers: forward AND backward run only kernels of libvilbert_hip.so.
+
+What torch autograd contributes is the graph bookkeeping (and the few gradient additions where a
+tensor feeds two consumers); every gradient *computation* below is a native kernel:
+dgrad / wgrad MFMA GEMMs (bias gradient fused into wgrad), GELU / ReLU backward, LayerNorm backward
+(deterministic two-stage column reduction), the two-pass attention backward, embedding scatter-add
+and the counter-based dropout mask that forward and backward regenerate from (seed, index).
+"""
+import itertools
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+_seed_counter = itertools.count(1)
+
+
+def next_seed():
+    """64-bit dropout seed: torch's initial seed (so torch.manual_seed makes runs repeatable) mixed
+    with a per-process call counter. No device sync."""
+    return ((torch.initial_seed() & 0xFFFFFFFF) * 0x9E3779B1 + next(_seed_counter) * 0x632BE59BD9B4E019) \
+        & 0xFFFFFFFFFFFFFFFF
+
+
+class LinearFn(Function):
+    """y = act(x @ cat(W).T + cat(b)) (+ residual). Inputs: x, residual, act, nseg, W..., b..."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act, nseg, *wb):
+        weights, biases = list(wb[:nseg]), list(wb[nseg:])
+        y, pre = ops.linear_fwd(x, weights, biases, act, residual, want_preact=act is not None)
+        ctx.save_for_backward(x, pre, *weights)
+        ctx.act, ctx.nseg = act, nseg
+        ctx.has_bias = [b is not None for b in biases]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre = ctx.saved_tensors[:2]
+        weights = list(ctx.saved_tensors[2:])
+        nseg, seg_n, K = ctx.nseg, weights[0].shape[0], weights[0].shape[1]
+        dy = dy.contiguous()
+        dres = dy if ctx.needs_input_grad[1] else None
+        dpre = ops.act_bwd(dy, pre, ctx.act) if ctx.act is not None else dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_bwd_input(dpre, weights, K).view(x.shape)
+        need_w = any(ctx.needs_input_grad[4:4 + nseg])
+        need_b = [ctx.has_bias[s] and ctx.needs_input_grad[4 + nseg + s] for s in range(nseg)]
+        dws, dbs = [None] * nseg, [None] * nseg
+        if need_w or any(need_b):
+            dws, dbs = ops.linear_bwd_weight(dpre, x, nseg, seg_n, need_b)
+        return (dx, dres, None, None) + tuple(dws) + tuple(dbs)
+
+
+class LayerNormFn(Function):
+    """TF-style LayerNorm of one tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, None, want_stats=True)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+        return dx.view(x.shape), dgamma, dbeta, None
+
+
+class DropoutFn(Function):
+    """y = dropout(x, p) (+ residual)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, p):
+        ctx.p, ctx.seed = p, next_seed()
+        return ops.dropout(x, p, ctx.seed, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ops.dropout(dy, ctx.p, ctx.seed) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.needs_input_grad[1] else None), None
+
+
+def dropout(x, p, residual=None):
+    return DropoutFn.apply(x, residual, p)
+
+
+class SelfAttnFn(Function):
+    """ctx = attention over one fused [q | k | v] projection; dqkv is written in one buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask_add, heads, drop_p, want_probs):
+        H = qkv.shape[-1] // 3
+        seed = next_seed() if drop_p > 0.0 else 0
+        out, probs, lse = ops.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads,
+                                            want_probs, True, drop_p, seed)
+        ctx.save_for_backward(qkv, mask_add, lse)
+        ctx.meta = (heads, drop_p, seed)
+        if probs is None:
+            probs = qkv.new_empty(0)
+        ctx.mark_non_differentiable(probs)
+        return out, probs
+
+    @staticmethod
+    def backward(ctx, d_out, _d_probs):
+        qkv, mask_add, lse = ctx.saved_tensors
+        heads, drop_p, seed = ctx.meta
+        H = qkv.shape[-1] // 3
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(d_out, qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads, lse,
+                          dqkv[..., :H], dqkv[..., H:2 * H], dqkv[..., 2 * H:], drop_p, seed)
+        return dqkv, None, None, None, None
+
+
+class BiAttnFn(Function):
+    """Both directions of the co-attention (reference vilbert.py:768-809) over the two fused projections:
+    ctx1 = attn(q2; k1, v1 | mask1) for the text stream, ctx2 = attn(q1; k2, v2 | mask2) for the image
+    stream. The backward fills dqkv1 / dqkv2 with each slice written exactly once."""
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, mask1, mask2, heads, p1, p2, want_probs):
+        H = qkv1.shape[-1] // 3
+        s1 = next_seed() if p1 > 0.0 else 0
+        s2 = next_seed() if p2 > 0.0 else 0
+        q1, k1, v1 = qkv1[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:]
+        q2, k2, v2 = qkv2[..., :H], qkv2[..., H:2 * H], qkv2[..., 2 * H:]
+        ctx1, probs1, lse1 = ops.attention_fwd(q2, k1, v1, mask1, heads, want_probs, True, p1, s1)
+        ctx2, probs2, lse2 = ops.attention_fwd(q1, k2, v2, mask2, heads, want_probs, True, p2, s2)
+        ctx.save_for_backward(qkv1, qkv2, mask1, mask2, lse1, lse2)
+        ctx.meta = (heads, p1, p2, s1, s2)
+        if probs1 is None:
+            probs1, probs2 = qkv1.new_empty(0), qkv1.new_empty(0)
+        ctx.mark_non_differentiable(probs1, probs2)
+        return ctx1, ctx2, probs1, probs2
+
+    @staticmethod
+    def backward(ctx, d1, d2, _dp1, _dp2):
+        qkv1, qkv2, mask1, mask2, lse1, lse2 = ctx.saved_tensors
+        heads, p1, p2, s1, s2 = ctx.meta
+        H = qkv1.shape[-1] // 3
+        sl = lambda t: (t[..., :H], t[..., H:2 * H], t[..., 2 * H:])
+        q1, k1, v1 = sl(qkv1)
+        q2, k2, v2 = sl(qkv2)
+        dqkv1, dqkv2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
+        dq1, dk1, dv1 = sl(dqkv1)
+        dq2, dk2, dv2 = sl(dqkv2)
+        ops.attention_bwd(d1, q2, k1, v1, mask1, heads, lse1, dq2, dk1, dv1, p1, s1)
+        ops.attention_bwd(d2, q1, k2, v2, mask2, heads, lse2, dq1, dk2, dv2, p2, s2)
+        return dqkv1, dqkv2, None, None, None, None, None, None
+
+
+class TextEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, ids, seg, word, pos, typ, gamma, beta, eps, task_ids, task_emb):
+        out, mean, rstd, presum = ops.text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids,
+                                                        task_emb, want_stats=True)
+        ctx.save_for_backward(ids, seg, task_ids, presum, mean, rstd, gamma)
+        ctx.shapes = (tuple(word.shape), tuple(pos.shape), tuple(typ.shape),
+                      tuple(task_emb.shape) if task_emb is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, seg, task_ids, presum, mean, rstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.layernorm_bwd(dy, presum, mean, rstd, gamma)
+        ws, ps, ts, ks = ctx.shapes
+        dword, dpos, dtype, dtask = ops.text_embed_bwd(dx, ids, seg, task_ids, ws, ps, ts, ks)
+        return None, None, dword, dpos, dtype, dgamma, dbeta, None, None, dtask
+
+
+class ImageEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, feat_proj, loc, w_loc, b_loc, gamma, beta, eps):
+        out, mean, rstd, presum = ops.image_embed_ln_fwd(feat_proj, loc, w_loc, b_loc, gamma, beta, eps,
+                                                         want_stats=True)
+        ctx.save_for_backward(loc, presum, mean, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        loc, presum, mean, rstd, gamma = ctx.saved_tensors
+        dsum, dgamma, dbeta = ops.layernorm_bwd(dy, presum, mean, rstd, gamma)
+        hidden = dsum.shape[-1]
+        (dw_loc,), (db_loc,) = ops.linear_bwd_weight(dsum, loc.reshape(-1, 5), 1, hidden, [True])
+        return dsum, None, dw_loc, db_loc, dgamma, dbeta, None

@@ -1,11 +1,12 @@
-"""Autograd-visible fused ops built on the native kernels.
+"""Fused ops of the model, autograd-visible.
 
-Each op is one ``torch.autograd.Function`` whose forward AND backward enqueue only kernels of
-libvilbert_hip.so. When no input needs a gradient (or grad mode is off) the forward launcher is
-called directly, with nothing saved.
+When no input needs a gradient (or grad mode is off) the forward launcher is called directly with
+nothing saved; otherwise the op goes through its ``torch.autograd.Function`` (autograd_ops.py), whose
+backward also runs native kernels only.
 """
 import torch
 
+from . import autograd_ops as A
 from . import ops
 
 
@@ -19,37 +20,63 @@ def linear(x, weights, biases=None, act=None, residual=None):
         weights, biases = [weights], [biases]
     if biases is None:
         biases = [None] * len(weights)
-    if _needs_grad(x, residual, *weights, *[b for b in biases if b is not None]):
-        from . import autograd_ops
-        return autograd_ops.LinearFn.apply(x, residual, act, len(weights), *weights, *biases)
+    if _needs_grad(x, residual, *weights, *biases):
+        return A.LinearFn.apply(x, residual, act, len(weights), *weights, *biases)
     return ops.linear_fwd(x, weights, biases, act, residual)[0]
 
 
-def layer_norm(x, gamma, beta, eps=1e-12, x2=None):
-    """TF-style LayerNorm of (x + x2)."""
-    if _needs_grad(x, x2, gamma, beta):
-        from . import autograd_ops
-        return autograd_ops.LayerNormFn.apply(x, x2, gamma, beta, eps)
-    return ops.layernorm_fwd(x, gamma, beta, eps, x2)[0]
+def layer_norm(x, gamma, beta, eps=1e-12):
+    if _needs_grad(x, gamma, beta):
+        return A.LayerNormFn.apply(x, gamma, beta, eps)
+    return ops.layernorm_fwd(x, gamma, beta, eps)[0]
 
 
-def attention(q, k, v, mask_add, heads, want_probs=False):
-    """softmax(q k^T / sqrt(d) + mask) v with merged heads; returns (context, probs or None)."""
-    if _needs_grad(q, k, v):
-        from . import autograd_ops
-        return autograd_ops.attention(q, k, v, mask_add, heads, want_probs)
-    return ops.attention_fwd(q, k, v, mask_add, heads, want_probs)
+def dropout(x, p, residual=None):
+    """dropout(x, p) (+ residual); p is the EFFECTIVE probability (0 in eval mode)."""
+    if p <= 0.0:
+        # identity (+ residual): the callers fuse the residual into the producing GEMM instead
+        assert residual is None
+        return x
+    if _needs_grad(x, residual):
+        return A.dropout(x, p, residual)
+    return ops.dropout(x, p, A.next_seed(), residual)
+
+
+def self_attention(qkv, mask_add, heads, drop_p=0.0, want_probs=False):
+    """Attention over a fused [B, S, 3H] = [q | k | v] projection. Returns (context [B,S,H], probs|None)."""
+    if _needs_grad(qkv):
+        out, probs = A.SelfAttnFn.apply(qkv, mask_add, heads, drop_p, want_probs)
+        return out, (probs if want_probs else None)
+    H = qkv.shape[-1] // 3
+    seed = A.next_seed() if drop_p > 0.0 else 0
+    out, probs, _ = ops.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads,
+                                      want_probs, False, drop_p, seed)
+    return out, probs
+
+
+def bi_attention(qkv1, qkv2, mask1, mask2, heads, p1=0.0, p2=0.0, want_probs=False):
+    """Co-attention between stream 1 (image, qkv1 / mask1) and stream 2 (text, qkv2 / mask2):
+    returns (ctx1 = attn(q2; k1, v1), ctx2 = attn(q1; k2, v2), probs1|None, probs2|None)."""
+    if _needs_grad(qkv1, qkv2):
+        c1, c2, pr1, pr2 = A.BiAttnFn.apply(qkv1, qkv2, mask1, mask2, heads, p1, p2, want_probs)
+        return c1, c2, (pr1 if want_probs else None), (pr2 if want_probs else None)
+    H = qkv1.shape[-1] // 3
+    s1 = A.next_seed() if p1 > 0.0 else 0
+    s2 = A.next_seed() if p2 > 0.0 else 0
+    c1, pr1, _ = ops.attention_fwd(qkv2[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:], mask1, heads,
+                                   want_probs, False, p1, s1)
+    c2, pr2, _ = ops.attention_fwd(qkv1[..., :H], qkv2[..., H:2 * H], qkv2[..., 2 * H:], mask2, heads,
+                                   want_probs, False, p2, s2)
+    return c1, c2, pr1, pr2
 
 
 def text_embed_ln(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None, task_emb=None):
     if _needs_grad(word, pos, typ, gamma, beta, task_emb):
-        from . import autograd_ops
-        return autograd_ops.TextEmbedFn.apply(ids, seg, word, pos, typ, gamma, beta, eps, task_ids, task_emb)
+        return A.TextEmbedFn.apply(ids, seg, word, pos, typ, gamma, beta, eps, task_ids, task_emb)
     return ops.text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids, task_emb)[0]
 
 
 def image_embed_ln(feat_proj, loc, w_loc, b_loc, gamma, beta, eps):
     if _needs_grad(feat_proj, w_loc, b_loc, gamma, beta):
-        from . import autograd_ops
-        return autograd_ops.ImageEmbedFn.apply(feat_proj, loc, w_loc, b_loc, gamma, beta, eps)
+        return A.ImageEmbedFn.apply(feat_proj, loc, w_loc, b_loc, gamma, beta, eps)
     return ops.image_embed_ln_fwd(feat_proj, loc, w_loc, b_loc, gamma, beta, eps)[0]

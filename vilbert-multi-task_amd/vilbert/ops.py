@@ -1,7 +1,7 @@
-"""Tensor-level entry points of the native layer (forward launchers).
+"""Tensor-level launchers of the native layer (forward and backward kernels).
 
-Every function here validates its tensors, allocates the outputs with ``torch.empty`` and enqueues
-exactly the kernels of include/vilbert_hip.h on the current stream. No torch arithmetic.
+Every function here validates its tensors, allocates the outputs with ``torch.empty`` / ``torch.zeros``
+and enqueues exactly the kernels of include/vilbert_hip.h on the current stream. No torch arithmetic.
 """
 import ctypes
 import math
@@ -11,8 +11,8 @@ import torch
 from . import _native as N
 
 
-# Optional per-launch timing of the GEMM kernel (bench.py's roofline leg): when enabled every
-# vb_linear_fwd launch is bracketed by HIP events recorded on the launch stream.
+# Optional per-launch timing of the GEMM kernel (bench.py's roofline leg): when enabled every GEMM
+# launch (forward, dgrad, wgrad) is bracketed by HIP events recorded on the launch stream.
 _PROFILE = {"on": False, "events": [], "flops": 0.0}
 
 
@@ -29,6 +29,18 @@ def profile_linear(enable):
     return out
 
 
+def _timed(fn, flops):
+    if not _PROFILE["on"]:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    _PROFILE["events"].append((e0, e1))
+    _PROFILE["flops"] += flops
+    return out
+
+
 def _rows(t):
     """[..., C] -> (rows, C) of a contiguous tensor."""
     return t.numel() // t.shape[-1], t.shape[-1]
@@ -36,6 +48,14 @@ def _rows(t):
 
 def _contig(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _row_view(x, K):
+    """2-D row-strided view (x2, ld, leading shape) of [..., K]; copies only if it has to."""
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K:
+        return x, x.stride(0), (x.shape[0],)
+    x = _contig(x)
+    return x.view(-1, K), K, tuple(x.shape[:-1])
 
 
 def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
@@ -50,13 +70,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
     nseg, seg_n, K = len(weights), weights[0].shape[0], weights[0].shape[1]
     if x.shape[-1] != K:
         raise RuntimeError("linear: input has %d features, weight expects %d" % (x.shape[-1], K))
-    # accept [rows..., K] views whose rows are uniformly strided
-    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= K:
-        x2, lda, lead = x, x.stride(0), (x.shape[0],)
-    else:
-        x = _contig(x)
-        lead = tuple(x.shape[:-1])
-        x2, lda = x.view(-1, K), K
+    x2, lda, lead = _row_view(x, K)
     M = x2.shape[0]
     n_out = nseg * seg_n
     y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
@@ -81,16 +95,73 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
     if pre is not None:
         a.preact, a.ldp = pre.data_ptr(), n_out
     a.act = N.ACT_CODES[act]
-    if _PROFILE["on"]:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd")
-        e1.record()
-        _PROFILE["events"].append((e0, e1))
-        _PROFILE["flops"] += 2.0 * M * n_out * K
-    else:
-        N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd")
+    _timed(lambda: N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd"),
+           2.0 * M * n_out * K)
     return y, pre
+
+
+def linear_bwd_input(dy, weights, in_features):
+    """dX = dY @ cat(weights) for dY [..., nseg*n]; returns [..., in_features]."""
+    nseg, seg_n = len(weights), weights[0].shape[0]
+    dy = _contig(dy)
+    M = dy.numel() // (nseg * seg_n)
+    dx = torch.empty(tuple(dy.shape[:-1]) + (in_features,), dtype=torch.float32, device=dy.device)
+    a = N.LinearBwdInputArgs()
+    a.M, a.K, a.nseg, a.seg_n = M, in_features, nseg, seg_n
+    a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), nseg * seg_n
+    for s in range(nseg):
+        a.W[s] = N.dev_f32(weights[s], "linear weight")
+    a.ldw = in_features
+    a.dX, a.ldx = dx.data_ptr(), in_features
+    a.accumulate = 0
+    _timed(lambda: N.check(N.lib().vb_linear_bwd_input(N.stream_ptr(), ctypes.byref(a)), "vb_linear_bwd_input"),
+           2.0 * M * nseg * seg_n * in_features)
+    return dx
+
+
+def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
+    """Per segment: dW_s = dY[:, s]^T @ X and db_s = colsum(dY[:, s]). Returns (list dW, list db or None)."""
+    dy = _contig(dy)
+    K = x.shape[-1]
+    x2, ldx, _ = _row_view(x, K)
+    M = x2.shape[0]
+    dws, dbs = [], []
+    for s in range(nseg):
+        dw = torch.empty(seg_n, K, dtype=torch.float32, device=dy.device)
+        db = torch.empty(seg_n, dtype=torch.float32, device=dy.device) if want_bias[s] else None
+        a = N.LinearBwdWeightArgs()
+        a.M, a.K, a.n = M, K, seg_n
+        a.dY, a.ldy = N.dev_f32(dy, "linear grad_output") + 4 * s * seg_n, nseg * seg_n
+        a.X, a.ldx = N.dev_f32(x2, "linear input"), ldx
+        a.dW, a.ldw = dw.data_ptr(), K
+        a.dbias = db.data_ptr() if db is not None else None
+        a.accumulate = 0
+        _timed(lambda: N.check(N.lib().vb_linear_bwd_weight(N.stream_ptr(), ctypes.byref(a)),
+                               "vb_linear_bwd_weight"), 2.0 * M * seg_n * K)
+        dws.append(dw)
+        dbs.append(db)
+    return dws, dbs
+
+
+def act_bwd(dy, preact, act):
+    dy, preact = _contig(dy), _contig(preact)
+    dx = torch.empty_like(dy)
+    N.check(N.lib().vb_act_bwd(N.stream_ptr(), dy.numel(), N.ACT_CODES[act], N.dev_f32(dy, "grad_output"),
+                               N.dev_f32(preact, "preactivation"), dx.data_ptr()), "vb_act_bwd")
+    return dx
+
+
+def dropout(x, p, seed, residual=None):
+    """x * keep(seed, i) / (1 - p) (+ residual); on a gradient with the same seed it is the backward."""
+    x = _contig(x)
+    if residual is not None:
+        residual = _contig(residual)
+        if residual.shape != x.shape:
+            raise RuntimeError("dropout: residual shape mismatch")
+    y = torch.empty_like(x)
+    N.check(N.lib().vb_dropout(N.stream_ptr(), x.numel(), N.dev_f32(x, "dropout input"),
+                               N.dev_f32(residual, "dropout residual"), y.data_ptr(), p, seed), "vb_dropout")
+    return y
 
 
 def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
@@ -112,8 +183,24 @@ def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
     return y, mean, rstd
 
 
+def layernorm_bwd(dy, x, mean, rstd, gamma):
+    """Returns (dx, dgamma, dbeta); x is the normalised input (the sum when the forward had x2)."""
+    dy, x = _contig(dy), _contig(x)
+    rows, cols = _rows(x)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = torch.empty(N.lib().vb_layernorm_bwd_workspace(rows, cols), dtype=torch.float32, device=x.device)
+    N.check(N.lib().vb_layernorm_bwd(
+        N.stream_ptr(), rows, cols, N.dev_f32(dy, "layernorm grad_output"), N.dev_f32(x, "layernorm input"),
+        N.dev_f32(mean, "layernorm mean"), N.dev_f32(rstd, "layernorm rstd"), N.dev_f32(gamma, "layernorm weight"),
+        dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr()), "vb_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
 def text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None, task_emb=None,
                       want_stats=False):
+    """Returns (out, mean, rstd, presum); the last three are None unless want_stats."""
     ids, seg = _contig(ids), _contig(seg)
     B, T = ids.shape
     H = word.shape[1]
@@ -121,10 +208,11 @@ def text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None,
         raise RuntimeError("sequence length %d exceeds max_position_embeddings %d" % (T, pos.shape[0]))
     n_out = T + (1 if task_ids is not None else 0)
     out = torch.empty(B, n_out, H, dtype=torch.float32, device=word.device)
-    mean = rstd = None
+    mean = rstd = presum = None
     if want_stats:
         mean = torch.empty(B * n_out, dtype=torch.float32, device=word.device)
         rstd = torch.empty(B * n_out, dtype=torch.float32, device=word.device)
+        presum = torch.empty_like(out)
     if task_ids is not None:
         task_ids = _contig(task_ids.view(-1))
         if task_ids.numel() != B:
@@ -135,28 +223,49 @@ def text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None,
         N.dev_f32(typ, "token_type_embeddings"), N.dev_i64(task_ids, "task_ids"),
         N.dev_f32(task_emb, "task_embeddings"), N.dev_f32(gamma, "LayerNorm.weight"),
         N.dev_f32(beta, "LayerNorm.bias"), eps, out.data_ptr(),
-        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None),
-        "vb_text_embed_ln_fwd")
-    return out, mean, rstd
+        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None,
+        presum.data_ptr() if want_stats else None), "vb_text_embed_ln_fwd")
+    return out, mean, rstd, presum
+
+
+def text_embed_bwd(dx, ids, seg, task_ids, word_shape, pos_shape, type_shape, task_shape):
+    """Scatter-add dx (gradient of the pre-LayerNorm sum) into fresh zero tables."""
+    dx = _contig(dx)
+    ids, seg = _contig(ids), _contig(seg)
+    B, T = ids.shape
+    dev = dx.device
+    dword = torch.zeros(word_shape, dtype=torch.float32, device=dev)
+    dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dev)
+    dtype = torch.zeros(type_shape, dtype=torch.float32, device=dev)
+    dtask = torch.zeros(task_shape, dtype=torch.float32, device=dev) if task_ids is not None else None
+    if task_ids is not None:
+        task_ids = _contig(task_ids.view(-1))
+    N.check(N.lib().vb_text_embed_bwd(
+        N.stream_ptr(), B, T, word_shape[1], N.dev_i64(ids, "input_ids"), N.dev_i64(seg, "token_type_ids"),
+        N.dev_i64(task_ids, "task_ids"), N.dev_f32(dx, "embedding grad"), dword.data_ptr(), dpos.data_ptr(),
+        dtype.data_ptr(), dtask.data_ptr() if dtask is not None else None), "vb_text_embed_bwd")
+    return dword, dpos, dtype, dtask
 
 
 def image_embed_ln_fwd(feat_proj, loc, w_loc, b_loc, gamma, beta, eps, want_stats=False):
+    """Returns (out, mean, rstd, presum)."""
     feat_proj, loc = _contig(feat_proj), _contig(loc)
     rows, H = _rows(feat_proj)
     if loc.shape[-1] != 5 or loc.numel() != rows * 5:
         raise RuntimeError("image_loc must be [..., 5] matching the features")
     out = torch.empty_like(feat_proj)
-    mean = rstd = None
+    mean = rstd = presum = None
     if want_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=out.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=out.device)
+        presum = torch.empty_like(out)
     N.check(N.lib().vb_image_embed_ln_fwd(
         N.stream_ptr(), rows, H, N.dev_f32(feat_proj, "image projection"), N.dev_f32(loc, "image_loc"),
         N.dev_f32(w_loc, "image_location_embeddings.weight"), N.dev_f32(b_loc, "image_location_embeddings.bias"),
         N.dev_f32(gamma, "LayerNorm.weight"), N.dev_f32(beta, "LayerNorm.bias"), eps, out.data_ptr(),
-        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None),
-        "vb_image_embed_ln_fwd")
-    return out, mean, rstd
+        mean.data_ptr() if want_stats else None, rstd.data_ptr() if want_stats else None,
+        presum.data_ptr() if want_stats else None), "vb_image_embed_ln_fwd")
+    return out, mean, rstd, presum
 
 
 def additive_mask(mask):
@@ -176,32 +285,57 @@ def additive_mask(mask):
     return out
 
 
-def attention_fwd(q, k, v, mask_add, heads, want_probs=False):
-    """q: [Bq, Sq, H*] view, k/v: [Bk, Sk, H*] views (last dim contiguous, uniform row stride, e.g. column
-    slices of a fused [q|k|v] projection); mask_add: [Bk, 1, 1, Sk] or [Bk, Sk] fp32 additive, or None.
-    Bq / Bk may be 1 against a larger batch (broadcast). Returns (ctx [B, Sq, H], probs or None)."""
+def _attn_args(q, k, v, mask_add, heads, drop_p, seed):
     Bq, Sq, H = q.shape
     Bk, Sk, _ = k.shape
     B = max(Bq, Bk)
     d = H // heads
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):
-        if t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+        if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
             raise RuntimeError("attention: %s must be a row-strided view" % nm)
-    out = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
-    probs = torch.empty(B, heads, Sq, Sk, dtype=torch.float32, device=q.device) if want_probs else None
     a = N.AttentionArgs()
     a.batch, a.heads, a.head_dim, a.n_q, a.n_k = B, heads, d, Sq, Sk
     a.q_batch, a.kv_batch = Bq, Bk
     a.Q, a.ldq = N.dev_f32(q, "attention q"), q.stride(1)
     a.K, a.ldk = N.dev_f32(k, "attention k"), k.stride(1)
     a.V, a.ldv = N.dev_f32(v, "attention v"), v.stride(1)
+    keep = []
     if mask_add is not None:
         mask_add = _contig(mask_add)
         if mask_add.numel() != Bk * Sk:
             raise RuntimeError("attention: mask must hold %d x %d values" % (Bk, Sk))
         a.mask_add = N.dev_f32(mask_add, "attention mask")
+        keep.append(mask_add)
+    a.scale = 1.0 / math.sqrt(d)
+    a.dropout_p, a.seed = float(drop_p), int(seed)
+    return a, keep, (B, Sq, Sk, H)
+
+
+def attention_fwd(q, k, v, mask_add, heads, want_probs=False, want_lse=False, drop_p=0.0, seed=0):
+    """q: [Bq, Sq, H*] view, k/v: [Bk, Sk, H*] views (last dim contiguous, uniform row stride, e.g. column
+    slices of a fused [q|k|v] projection); mask_add: [Bk, 1, 1, Sk] or [Bk, Sk] fp32 additive, or None.
+    Bq / Bk may be 1 against a larger batch (broadcast). Returns (ctx [B, Sq, H], probs|None, lse|None)."""
+    a, keep, (B, Sq, Sk, H) = _attn_args(q, k, v, mask_add, heads, drop_p, seed)
+    out = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
+    probs = torch.empty(B, heads, Sq, Sk, dtype=torch.float32, device=q.device) if want_probs else None
+    lse = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device) if want_lse else None
     a.O, a.ldo = out.data_ptr(), H
     a.probs = probs.data_ptr() if want_probs else None
-    a.scale = 1.0 / math.sqrt(d)
+    a.lse = lse.data_ptr() if want_lse else None
     N.check(N.lib().vb_attention_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_attention_fwd")
-    return out, probs
+    return out, probs, lse
+
+
+def attention_bwd(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p=0.0, seed=0):
+    """Writes dq / dk / dv (row-strided views, e.g. column slices of a fused gradient buffer) in place."""
+    a, keep, (B, Sq, Sk, H) = _attn_args(q, k, v, mask_add, heads, drop_p, seed)
+    d_out = _contig(d_out)
+    a.lse = N.dev_f32(lse, "attention lse")
+    g = N.AttentionGrads()
+    g.dO, g.lddo = N.dev_f32(d_out, "attention grad_output"), H
+    g.dQ, g.lddq = N.dev_f32(dq, "attention dq"), dq.stride(1)
+    g.dK, g.lddk = N.dev_f32(dk, "attention dk"), dk.stride(1)
+    g.dV, g.lddv = N.dev_f32(dv, "attention dv"), dv.stride(1)
+    dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
+    g.dvec = dvec.data_ptr()
+    N.check(N.lib().vb_attention_bwd(N.stream_ptr(), ctypes.byref(a), ctypes.byref(g)), "vb_attention_bwd")

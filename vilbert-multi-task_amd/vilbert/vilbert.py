@@ -96,11 +96,7 @@ def _drop_p(dropout_module):
 
 
 def _dropout(x, dropout_module):
-    p = _drop_p(dropout_module)
-    if p > 0.0:
-        from . import autograd_ops
-        return autograd_ops.dropout(x, p)
-    return x
+    return F.dropout(x, _drop_p(dropout_module))
 
 
 class BertLayerNorm(nn.Module):
@@ -112,8 +108,8 @@ class BertLayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(hidden_size))
         self.variance_epsilon = eps
 
-    def forward(self, x, residual=None):
-        return F.layer_norm(x, self.weight, self.bias, self.variance_epsilon, residual)
+    def forward(self, x):
+        return F.layer_norm(x, self.weight, self.bias, self.variance_epsilon)
 
 
 class BertEmbeddings(nn.Module):
@@ -167,21 +163,16 @@ def _self_attention(mod, hidden_states, attention_mask, gates=None):
     H = mod.all_head_size
     qkv = F.linear(hidden_states, [mod.query.weight, mod.key.weight, mod.value.weight],
                    [mod.query.bias, mod.key.bias, mod.value.bias])
-    q, k, v = qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:]
-    if gates is not None:  # dynamic_attention (:577-586): small elementwise gate, kept in torch
-        q, k = q * gates[0].unsqueeze(1), k * gates[1].unsqueeze(1)
-    p = _drop_p(mod.dropout)
-    if p > 0.0:
-        from . import autograd_ops
-        ctx, probs = autograd_ops.attention(q, k, v, attention_mask, mod.num_attention_heads,
-                                            mod.visualization, drop_p=p)
-    else:
-        ctx, probs = F.attention(q, k, v, attention_mask, mod.num_attention_heads, mod.visualization)
+    if gates is not None:  # dynamic_attention (:577-586): rare path, small elementwise gates kept in torch
+        qkv = torch.cat([qkv[..., :H] * gates[0].unsqueeze(1), qkv[..., H:2 * H] * gates[1].unsqueeze(1),
+                         qkv[..., 2 * H:]], dim=-1)
+    ctx, probs = F.self_attention(qkv, attention_mask, mod.num_attention_heads, _drop_p(mod.dropout),
+                                  mod.visualization)
     attn_data = None
     if mod.visualization:
-        B, S = q.shape[0], q.shape[1]
+        B, S = qkv.shape[0], qkv.shape[1]
         split = lambda t: t.reshape(B, S, mod.num_attention_heads, mod.attention_head_size).permute(0, 2, 1, 3)
-        attn_data = {"attn": probs, "queries": split(q), "keys": split(k)}
+        attn_data = {"attn": probs, "queries": split(qkv[..., :H]), "keys": split(qkv[..., H:2 * H])}
     return ctx, attn_data
 
 
@@ -206,6 +197,15 @@ class BertSelfAttention(nn.Module):
         return _self_attention(self, hidden_states, attention_mask)
 
 
+def _dense_dropout_add_norm(dense, dropout, norm, hidden_states, input_tensor):
+    """LayerNorm(dropout(dense(h)) + input). Eval / p = 0: bias + residual are the GEMM epilogue.
+    Training: the dropout kernel applies the mask and adds the residual in one pass."""
+    p = _drop_p(dropout)
+    if p > 0.0:
+        return norm(F.dropout(F.linear(hidden_states, dense.weight, dense.bias), p, residual=input_tensor))
+    return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor))
+
+
 class _ResidualNormOutput(nn.Module):
     """LayerNorm(dropout(dense(h)) + input): BertSelfOutput / BertOutput / BertImageSelfOutput /
     BertImageOutput (reference vilbert.py:463-474, 506-517, 622-633, 667-678)."""
@@ -217,13 +217,7 @@ class _ResidualNormOutput(nn.Module):
         self.dropout = nn.Dropout(dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        p = _drop_p(self.dropout)
-        if p > 0.0:
-            h = _dropout(F.linear(hidden_states, self.dense.weight, self.dense.bias), self.dropout)
-            return self.LayerNorm(h, input_tensor)
-        # bias + residual fused into the GEMM epilogue, then one LayerNorm pass
-        h = F.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
-        return self.LayerNorm(h)
+        return _dense_dropout_add_norm(self.dense, self.dropout, self.LayerNorm, hidden_states, input_tensor)
 
 
 class BertSelfOutput(_ResidualNormOutput):
@@ -383,13 +377,6 @@ class BertBiAttention(nn.Module):
         self.value2 = nn.Linear(config.hidden_size, self.all_head_size)
         self.dropout2 = nn.Dropout(config.attention_probs_dropout_prob)
 
-    def _attend(self, q, k, v, mask, dropout):
-        p = _drop_p(dropout)
-        if p > 0.0:
-            from . import autograd_ops
-            return autograd_ops.attention(q, k, v, mask, self.num_attention_heads, self.visualization, drop_p=p)
-        return F.attention(q, k, v, mask, self.num_attention_heads, self.visualization)
-
     def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
                 use_co_attention_mask=False):
         H = self.all_head_size
@@ -397,18 +384,17 @@ class BertBiAttention(nn.Module):
                         [self.query1.bias, self.key1.bias, self.value1.bias])
         qkv2 = F.linear(input_tensor2, [self.query2.weight, self.key2.weight, self.value2.weight],
                         [self.query2.bias, self.key2.bias, self.value2.bias])
-        q1, k1, v1 = qkv1[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:]
-        q2, k2, v2 = qkv2[..., :H], qkv2[..., H:2 * H], qkv2[..., 2 * H:]
-        # text queries over image keys / values -> context for the TEXT stream (:768-785)
-        context_layer1, probs1 = self._attend(q2, k1, v1, attention_mask1, self.dropout1)
-        # image queries over text keys / values -> context for the IMAGE stream (:787-809)
-        context_layer2, probs2 = self._attend(q1, k2, v2, attention_mask2, self.dropout2)
+        # context_layer1: text queries over image keys / values -> TEXT stream (:768-785, dropout1)
+        # context_layer2: image queries over text keys / values -> IMAGE stream (:787-809, dropout2)
+        context_layer1, context_layer2, probs1, probs2 = F.bi_attention(
+            qkv1, qkv2, attention_mask1, attention_mask2, self.num_attention_heads, _drop_p(self.dropout1),
+            _drop_p(self.dropout2), self.visualization)
         attn_data = None
         if self.visualization:
             nh, hd = self.num_attention_heads, self.attention_head_size
             split = lambda t: t.reshape(t.shape[0], t.shape[1], nh, hd).permute(0, 2, 1, 3)
-            attn_data = {"attn1": probs1, "queries1": split(q2), "keys1": split(k1),
-                         "attn2": probs2, "querues2": split(q1), "keys2": split(k2)}
+            attn_data = {"attn1": probs1, "queries1": split(qkv2[..., :H]), "keys1": split(qkv1[..., H:2 * H]),
+                         "attn2": probs2, "querues2": split(qkv1[..., :H]), "keys2": split(qkv2[..., H:2 * H])}
         return context_layer1, context_layer2, attn_data
 
 
@@ -429,15 +415,9 @@ class BertBiOutput(nn.Module):
         self.q_dense2 = nn.Linear(config.bi_hidden_size, config.hidden_size)
         self.q_dropout2 = nn.Dropout(config.hidden_dropout_prob)
 
-    @staticmethod
-    def _branch(dense, norm, dropout, hidden_states, input_tensor):
-        if _drop_p(dropout) > 0.0:
-            return norm(_dropout(F.linear(hidden_states, dense.weight, dense.bias), dropout), input_tensor)
-        return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor))
-
     def forward(self, hidden_states1, input_tensor1, hidden_states2, input_tensor2):
-        out1 = self._branch(self.dense1, self.LayerNorm1, self.dropout1, hidden_states1, input_tensor1)
-        out2 = self._branch(self.dense2, self.LayerNorm2, self.dropout2, hidden_states2, input_tensor2)
+        out1 = _dense_dropout_add_norm(self.dense1, self.dropout1, self.LayerNorm1, hidden_states1, input_tensor1)
+        out2 = _dense_dropout_add_norm(self.dense2, self.dropout2, self.LayerNorm2, hidden_states2, input_tensor2)
         return out1, out2
 
 
