@@ -75,7 +75,7 @@ def test_dropout_mask_is_a_function_of_seed_and_index(ops):
     g = _rand(1000, 999, seed=5).cuda()
     r = _rand(1000, 999, seed=6).cuda()
     assert torch.equal(ops.dropout(g, 0.1, 1234), g * y1)
-    assert torch.allclose(ops.dropout(g, 0.1, 1234, r), g * y1 + r)
+    assert torch.allclose(ops.dropout(g, 0.1, 1234, r), g * y1 + r, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("rows,cols", [(37, 64), (300, 768), (129, 1024), (5, 2048)])
@@ -179,17 +179,24 @@ def _grad_parity(cfg, kind, batch, n_tok, n_reg, seed=5):
     helpers.assert_close(loss_g, loss_w, "loss", atol=1e-4 * max(1.0, abs(loss_w.item())))
     loss_g.backward()
     loss_w.backward()
+    # Criterion per parameter tensor: |got - ref| <= 2e-4 * max|ref| + 2e-7 * (largest gradient entry in
+    # the model). The second term only matters for gradients that are pure rounding noise in BOTH
+    # implementations (e.g. key.bias: softmax is invariant to a constant shift of the keys, so its true
+    # gradient is 0). Returns the worst error relative to that bound.
+    gmax = max(v.grad.abs().max().item() for v in leaves.values() if v.grad is not None)
     worst = 0.0
     for name, p in model.named_parameters():
         ref = leaves[name].grad
-        if ref is None or ref.abs().max() == 0:
+        if ref is None:
             assert p.grad is None or p.grad.abs().max().item() == 0.0, name
             continue
         assert p.grad is not None, name
-        scale = max(ref.abs().max().item(), 1e-6)
+        scale = ref.abs().max().item()
         err = (p.grad.cpu().double() - ref.double()).abs().max().item()
-        assert err <= 2e-4 * scale + 1e-6, "%s: grad err %.3e vs scale %.3e" % (name, err, scale)
-        worst = max(worst, err / scale)
+        bound = 2e-4 * scale + 2e-7 * gmax
+        assert err <= bound, "%s: grad err %.3e > bound %.3e (max|ref| %.3e, model max %.3e)" % (
+            name, err, bound, scale, gmax)
+        worst = max(worst, err / bound)
     return worst
 
 
@@ -205,7 +212,7 @@ def test_model_gradients_match_oracle_autograd(kind, over):
     cfg = synth.tiny_config(**NO_DROPOUT, **over)
     # the wrappers hard-code nn.Dropout(0.1) on the pooled output (vilbert.py:1226,1606), so train mode
     # is made deterministic by forcing every effective dropout probability to 0
-    assert _grad_parity_no_dropout(cfg, kind) < 2e-4
+    assert _grad_parity_no_dropout(cfg, kind) <= 1.0
 
 
 def _grad_parity_no_dropout(cfg, kind):
@@ -224,7 +231,7 @@ def test_model_gradients_base_2l2c():
     orig = V._drop_p
     V._drop_p = lambda m: 0.0
     try:
-        assert _grad_parity(cfg, "pretraining", 4, 20, 37) < 2e-4
+        assert _grad_parity(cfg, "pretraining", 4, 20, 37) <= 1.0
     finally:
         V._drop_p = orig
 

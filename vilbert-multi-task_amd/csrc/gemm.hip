@@ -27,12 +27,19 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int KC_LD = 36;    // k-contiguous LDS row stride
-constexpr int RC_LD = 132;   // row-contiguous LDS row stride
-constexpr int OPER_SZ = 128 * KC_LD;          // 4608 floats (>= 32 * 132 = 4224)
-constexpr int STAGE_SZ = 2 * OPER_SZ;         // A + B
-constexpr int GEMM_LDS_BYTES = 2 * STAGE_SZ * 4;  // 73,728 B
+constexpr int BM = 128, BN = 128;
+constexpr int RC_LD = 132;   // row-contiguous LDS row stride ([BK][132])
+
+// K-step dependent geometry. k-contiguous LDS rows hold BK + 4 floats: (BK + 4) / 4 is odd for
+// BK = 16 / 32, so the 16-lane ds_read_b128 groups fall on 16 distinct 16-byte slots (conflict free).
+template <int BK> struct Geo {
+    static constexpr int KC_LD = BK + 4;
+    static constexpr int OPER_SZ = 128 * KC_LD;      // >= BK * RC_LD
+    static constexpr int STAGE_SZ = 2 * OPER_SZ;     // A + B
+    static constexpr int LDS_BYTES = 2 * STAGE_SZ * 4;  // double buffered: 73,728 B (BK 32), 40,960 B (BK 16)
+    static constexpr int NLD = BK / 8;               // float4 loads per thread per operand tile
+    static constexpr int KQ = BK / 4;                // float4 per k-contiguous row
+};
 
 struct GemmP {
     int M, N, K;
@@ -53,10 +60,10 @@ struct GemmP {
 // k-contiguous operand (global [rows][ld]): thread t owns rows (t >> 3) + 32 it, it = 0..3, and the
 // four k values 4 (t & 7) .. +3 of every K tile, so the row base pointers are computed once per
 // block (this is also where a row is mapped to its weight segment).
-template <bool VEC>
-__device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[4], const float* const (&rowp)[4], int k, int K) {
+template <bool VEC, int NLD>
+__device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[NLD], const float* const (&rowp)[NLD], int k, int K) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NLD; ++it) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (rowp[it] != nullptr) {
             const float* g = rowp[it] + k;
@@ -74,11 +81,11 @@ __device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[4], const float* const
 
 // row-contiguous operand (global [k][ld], rows contiguous): thread t owns k = (t >> 5) + 8 it and the
 // four rows row0 + 4 (t & 31) .. +3.
-template <bool VEC>
-__device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[4], const float* __restrict__ base, long ld,
+template <bool VEC, int NLD>
+__device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[NLD], const float* __restrict__ base, long ld,
                                              int row0, int nrows, int k0, int K, int tid) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NLD; ++it) {
         const int f = tid + 256 * it;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
@@ -96,19 +103,22 @@ __device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[4], const float* __res
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&reg)[4], int tid) {
+template <bool KC, int BK>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&reg)[BK / 8], int tid) {
+    constexpr int KQ = BK / 4;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < BK / 8; ++it) {
         const int f = tid + 256 * it;
-        const int off = KC ? (f >> 3) * KC_LD + (f & 7) * 4 : (f >> 5) * RC_LD + (f & 31) * 4;
+        const int off = KC ? (f / KQ) * (BK + 4) + (f % KQ) * 4 : (f >> 5) * RC_LD + (f & 31) * 4;
         *reinterpret_cast<f32x4*>(s + off) = reg[it];
     }
 }
 
-template <bool A_KC, bool B_KC, bool VEC>
+template <bool A_KC, bool B_KC, bool VEC, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    using G = Geo<BK>;
+    constexpr int KC_LD = G::KC_LD, OPER_SZ = G::OPER_SZ, STAGE_SZ = G::STAGE_SZ, NLD = G::NLD, KQ = G::KQ;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -131,12 +141,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
     // Row base pointers of the k-contiguous operands. B rows (= output columns) are mapped to their
     // weight segment here: the segments are stacked along N (q | k | v projections in one launch).
-    const float* arow[4] = {nullptr, nullptr, nullptr, nullptr};
-    const float* brow[4] = {nullptr, nullptr, nullptr, nullptr};
-    const int kq = (tid & 7) * 4;
+    const float* arow[NLD];
+    const float* brow[NLD];
+    const int kq = (tid % KQ) * 4;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int r = (tid >> 3) + 32 * it;
+    for (int it = 0; it < NLD; ++it) {
+        arow[it] = nullptr;
+        brow[it] = nullptr;
+        const int r = tid / KQ + (256 / KQ) * it;
         if (A_KC && m0 + r < p.M) arow[it] = p.A + (long)(m0 + r) * p.lda;
         if (B_KC && n0 + r < p.N) {
             const int n = n0 + r, sg = n / p.bseg;
@@ -152,25 +164,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NLD], rb[NLD];
     float csum = 0.f;
 
     auto load_ab = [&](int kt) {
         const int k0 = kt * BK;
-        if (A_KC) load_tile_kc<VEC>(ra, arow, k0 + kq, p.K);
-        else load_tile_rc<VEC>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
+        if (A_KC) load_tile_kc<VEC, NLD>(ra, arow, k0 + kq, p.K);
+        else load_tile_rc<VEC, NLD>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
         if (B_KC) {
-            load_tile_kc<VEC>(rb, brow, k0 + kq, p.K);
+            load_tile_kc<VEC, NLD>(rb, brow, k0 + kq, p.K);
         } else {
             // segments stacked along K (dgrad through stacked weights); bseg is a multiple of BK
             const int sg = k0 / p.bseg;
-            load_tile_rc<VEC>(rb, p.B[sg], p.ldb, n0, p.N, k0 - sg * p.bseg, min(p.bseg, p.K - sg * p.bseg), tid);
+            load_tile_rc<VEC, NLD>(rb, p.B[sg], p.ldb, n0, p.N, k0 - sg * p.bseg, min(p.bseg, p.K - sg * p.bseg), tid);
         }
     };
 
     load_ab(kt_begin);
-    store_tile<A_KC>(smem, ra, tid);
-    store_tile<B_KC>(smem + OPER_SZ, rb, tid);
+    store_tile<A_KC, BK>(smem, ra, tid);
+    store_tile<B_KC, BK>(smem + OPER_SZ, rb, tid);
     __syncthreads();
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         if (more) load_ab(kt + 1);
 
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
+        for (int kc = 0; kc < BK / 8; ++kc) {
             f32x4 af[2], bf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -220,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
         if (more) {
             float* dA = smem + (cur ^ 1) * STAGE_SZ;
-            store_tile<A_KC>(dA, ra, tid);
-            store_tile<B_KC>(dA + OPER_SZ, rb, tid);
+            store_tile<A_KC, BK>(dA, ra, tid);
+            store_tile<B_KC, BK>(dA + OPER_SZ, rb, tid);
         }
         __syncthreads();
     }
@@ -262,23 +274,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
 }
 
-template <bool A_KC, bool B_KC>
-int launch_gemm(hipStream_t st, const GemmP& p, bool vec, int splits) {
+constexpr int BK_DEFAULT = 16;
+
+inline int gemm_bk() {
+    // K step of the GEMM kernels; VB_GEMM_BK=32 selects the 72 KiB double buffer (tuning knob).
+    static int bk = [] {
+        const char* e = getenv("VB_GEMM_BK");
+        const int v = e ? atoi(e) : BK_DEFAULT;
+        return v == 32 ? 32 : 16;
+    }();
+    return bk;
+}
+
+template <bool A_KC, bool B_KC, bool VEC, int BK>
+int launch_gemm_bk(hipStream_t st, const GemmP& p, int splits) {
     dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
-    // > 64 KiB of dynamic LDS needs the attribute once per kernel (per process).
-    static bool attr_done[2] = {false, false};
-    auto kv = gemm_f32_kernel<A_KC, B_KC, true>;
-    auto ks = gemm_f32_kernel<A_KC, B_KC, false>;
-    auto k = vec ? kv : ks;
-    if (!attr_done[vec]) {
+    auto k = gemm_f32_kernel<A_KC, B_KC, VEC, BK>;
+    static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the attribute once per kernel
+    if (Geo<BK>::LDS_BYTES > 65536 && !attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Geo<BK>::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_done[vec] = true;
+        attr_done = true;
     }
-    hipLaunchKernelGGL(k, grid, block, GEMM_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(k, grid, block, Geo<BK>::LDS_BYTES, st, p);
     VB_LAUNCH_CHECK();
     return 0;
+}
+
+template <bool A_KC, bool B_KC>
+int launch_gemm(hipStream_t st, const GemmP& p, bool vec, int splits) {
+    if (gemm_bk() == 32)
+        return vec ? launch_gemm_bk<A_KC, B_KC, true, 32>(st, p, splits)
+                   : launch_gemm_bk<A_KC, B_KC, false, 32>(st, p, splits);
+    return vec ? launch_gemm_bk<A_KC, B_KC, true, 16>(st, p, splits)
+               : launch_gemm_bk<A_KC, B_KC, false, 16>(st, p, splits);
 }
 
 }  // namespace
@@ -305,7 +335,7 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     p.act = a->act; p.accumulate = 0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    p.ktiles_per_split = (p.K + BK - 1) / BK;
+    p.ktiles_per_split = (p.K + gemm_bk() - 1) / gemm_bk();
     return launch_gemm<true, true>(static_cast<hipStream_t>(stream), p, vec, 1);
 }
 
@@ -317,6 +347,7 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
     hipStream_t st = static_cast<hipStream_t>(stream);
     // a K tile of the contraction (over out-features) must not straddle two weight segments; otherwise
     // run one launch per segment, accumulating.
+    const int BK = gemm_bk();
     const bool fused = a->nseg == 1 || (a->seg_n % BK) == 0;
     const int launches = fused ? 1 : a->nseg;
     for (int l = 0; l < launches; ++l) {
@@ -367,6 +398,7 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
     p.colsum = a->dbias;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    const int BK = gemm_bk();
     const int kt_total = (p.K + BK - 1) / BK;
     const int tiles = p.tiles_m * p.tiles_n;
     int splits = (1024 + tiles - 1) / tiles;  // aim at ~4 blocks per CU

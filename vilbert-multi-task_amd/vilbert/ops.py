@@ -68,6 +68,8 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
     if not isinstance(weights, (list, tuple)):
         weights, biases = [weights], [biases]
     nseg, seg_n, K = len(weights), weights[0].shape[0], weights[0].shape[1]
+    if nseg > N.VB_MAX_SEGMENTS:
+        raise RuntimeError("linear: at most %d weight segments per launch" % N.VB_MAX_SEGMENTS)
     if x.shape[-1] != K:
         raise RuntimeError("linear: input has %d features, weight expects %d" % (x.shape[-1], K))
     x2, lda, lead = _row_view(x, K)
