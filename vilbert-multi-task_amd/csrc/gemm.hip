@@ -54,6 +54,8 @@ struct GemmP {
     int tiles_m, tiles_n;
     int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
     float* colsum;        // row-contiguous A only: colsum[i] += sum_k A[i][k] (bias gradient), may be null
+    int epi;              // EPI_* fast path of interior tiles (EPI_GENERIC = none)
+    int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
 };
 
 // Staging of one 128 x 32 operand tile into registers (4 float4 per thread).
@@ -111,6 +113,36 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&
         const int f = tid + 256 * it;
         const int off = KC ? (f / KQ) * (BK + 4) + (f % KQ) * 4 : (f >> 5) * RC_LD + (f & 31) * 4;
         *reinterpret_cast<f32x4*>(s + off) = reg[it];
+    }
+}
+
+enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC };
+
+// Branch-free epilogue of a full interior tile. MODE: STORE c = v; GELU c = gelu(v); RES c = v + R;
+// PRE_GELU P = v, c = gelu(v); ACCUM c += v; ATOMIC atomicAdd(c, v)   with v = acc + bias.
+template <int MODE>
+__device__ __forceinline__ void epilogue_full(const GemmP& p, const f32x16 (&acc)[2][2], const float (&bv)[2],
+                                              int row0, int col0) {
+    float* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
+    const float* __restrict__ rbase = MODE == EPI_RES ? p.R + (long)row0 * p.ldr + col0 : nullptr;
+    float* __restrict__ pbase = MODE == EPI_PRE_GELU ? p.P + (long)row0 * p.ldp + col0 : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v = acc[i][j][r] + bv[j];
+                float* c = cbase + (long)dr * p.ldc + j * 32;
+                if (MODE == EPI_PRE_GELU) pbase[(long)dr * p.ldp + j * 32] = v;
+                if (MODE == EPI_GELU || MODE == EPI_PRE_GELU) v = gelu_erf(v);
+                if (MODE == EPI_RES) v += rbase[(long)dr * p.ldr + j * 32];
+                if (MODE == EPI_ATOMIC) unsafeAtomicAdd(c, v);
+                else if (MODE == EPI_ACCUM) *c += v;
+                else *c = v;
+            }
+        }
     }
 }
 
@@ -192,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         const bool more = kt + 1 < kt_end;
         if (more) load_ab(kt + 1);
 
+        if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             f32x4 af[2], bf[2];
@@ -224,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
                                                                         acc[i][j], 0, 0, 0);
         }
 
+        if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
         if (!A_KC && p.colsum != nullptr && n0 == 0 && tid < BM) {
             // bias gradient fused into wgrad: A = dY^T, so the sum over this K tile of row i = tid
 #pragma unroll
@@ -242,25 +276,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         unsafeAtomicAdd(p.colsum + m0 + tid, csum);
 
     // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    const bool split = gridDim.y > 1;
+    // Interior tiles with one of the common epilogues take a branch-free specialised path (the generic
+    // predicated loop costs ~2k VALU instructions per wave, during which the matrix pipe starves when
+    // the co-resident blocks reach their epilogues together).
     const bool lead = blockIdx.y == 0;  // bias / residual are added by one split only
+    float bv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= p.N) continue;
-        float bv = 0.f;
-        {
-            const int s = col / p.bseg;  // bias follows the N segmentation of a k-contiguous B
-            const float* bp = B_KC ? p.bias[s] : p.bias[0];
-            if (bp != nullptr && lead) bv = bp[B_KC ? col - s * p.bseg : col];
+        bv[j] = 0.f;
+        if (col < p.N && lead) {
+            const int sg = B_KC ? col / p.bseg : 0;  // bias follows the N segmentation of a k-contiguous B
+            const float* bp = p.bias[sg];
+            if (bp != nullptr) bv[j] = bp[col - sg * p.bseg * (B_KC ? 1 : 0)];
         }
+    }
+    const int row0 = m0 + wm * 64 + 4 * hi, col0 = n0 + wn * 64 + l31;
+    if (m0 + BM <= p.M && n0 + BN <= p.N && p.epi != EPI_GENERIC) {
+        switch (p.epi) {
+            case EPI_STORE: epilogue_full<EPI_STORE>(p, acc, bv, row0, col0); break;
+            case EPI_GELU: epilogue_full<EPI_GELU>(p, acc, bv, row0, col0); break;
+            case EPI_RES: epilogue_full<EPI_RES>(p, acc, bv, row0, col0); break;
+            case EPI_PRE_GELU: epilogue_full<EPI_PRE_GELU>(p, acc, bv, row0, col0); break;
+            case EPI_ACCUM: epilogue_full<EPI_ACCUM>(p, acc, bv, row0, col0); break;
+            default: epilogue_full<EPI_ATOMIC>(p, acc, bv, row0, col0); break;
+        }
+        return;
+    }
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.N) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] + bv[j];
                 if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
                 if (p.act == VB_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
@@ -303,7 +357,9 @@ int launch_gemm_bk(hipStream_t st, const GemmP& p, int splits) {
 }
 
 template <bool A_KC, bool B_KC>
-int launch_gemm(hipStream_t st, const GemmP& p, bool vec, int splits) {
+int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
+    static const int flags = [] { const char* e = getenv("VB_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
+    p.flags = flags;
     if (gemm_bk() == 32)
         return vec ? launch_gemm_bk<A_KC, B_KC, true, 32>(st, p, splits)
                    : launch_gemm_bk<A_KC, B_KC, false, 32>(st, p, splits);
@@ -333,6 +389,9 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     p.R = a->residual; p.ldr = a->ldr;
     p.P = a->preact; p.ldp = a->ldp;
     p.act = a->act; p.accumulate = 0;
+    if (a->act == VB_ACT_NONE && a->preact == nullptr) p.epi = a->residual != nullptr ? EPI_RES : EPI_STORE;
+    else if (a->act == VB_ACT_GELU && a->residual == nullptr) p.epi = a->preact != nullptr ? EPI_PRE_GELU : EPI_GELU;
+    else p.epi = EPI_GENERIC;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.ktiles_per_split = (p.K + gemm_bk() - 1) / gemm_bk();
@@ -367,6 +426,7 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
         p.C = a->dX; p.ldc = a->ldx;
         p.act = VB_ACT_NONE;
         p.accumulate = (a->accumulate || l > 0) ? 1 : 0;
+        p.epi = p.accumulate ? EPI_ACCUM : EPI_STORE;
         p.tiles_m = (p.M + BM - 1) / BM;
         p.tiles_n = (p.N + BN - 1) / BN;
         p.ktiles_per_split = (p.K + BK - 1) / BK;
@@ -408,5 +468,6 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
     splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
     const bool vec = (a->n % 4 == 0) && (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) &&
                      vb_aligned16(a->dY) && vb_aligned16(a->X);
+    p.epi = splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
     return launch_gemm<false, false>(st, p, vec, splits);
 }

@@ -802,10 +802,16 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v, all_attention_mask = self.bert(
             input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
             output_all_encoded_layers=False, output_all_attention_masks=output_all_attention_masks)
+        with_labels = not (masked_lm_labels is None or next_sentence_label is None or image_target is None)
+        if with_labels and self.visual_target in (0, 1):
+            losses = self._losses_at_labelled_positions(sequence_output_t, sequence_output_v, pooled_output_t,
+                                                        pooled_output_v, masked_lm_labels, image_label,
+                                                        image_target, next_sentence_label)
+            if losses is not None:
+                return losses
         prediction_scores_t, prediction_scores_v, seq_relationship_score = self.cls(
             sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v)
-
-        if masked_lm_labels is None or next_sentence_label is None or image_target is None:
+        if not with_labels:
             return prediction_scores_t, prediction_scores_v, seq_relationship_score, all_attention_mask
 
         prediction_scores_v = prediction_scores_v[:, 1:]
@@ -824,6 +830,45 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         masked_lm_loss = self.loss_fct(prediction_scores_t.view(-1, self.config.vocab_size),
                                        masked_lm_labels.view(-1))
         next_sentence_loss = self.loss_fct(seq_relationship_score.view(-1, 2), next_sentence_label.view(-1))
+        return masked_lm_loss.unsqueeze(0), masked_img_loss.unsqueeze(0), next_sentence_loss.unsqueeze(0)
+
+    def _losses_at_labelled_positions(self, sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v,
+                                      masked_lm_labels, image_label, image_target, next_sentence_label):
+        """The three pre-training losses with the heads evaluated ONLY where a label exists (~15 % of the
+        tokens / regions): CrossEntropy(ignore_index=-1) ignores every other token row and the region loss
+        multiplies every other region row by zero (reference vilbert.py:1506-1522,1578-1585), so the value
+        and every gradient are the same while the [B,T,30522] logits tensor (1.1 GB at B=256) and 85 % of
+        the two decoder GEMMs never exist. Costs one host sync for the row counts (the reference's training
+        loop syncs every step anyway, train_concap.py:589-598). Returns None when nothing is labelled (the
+        caller then takes the reference-shaped path, which yields the reference's NaN)."""
+        cls = self.cls
+        lm_flat = masked_lm_labels.reshape(-1)
+        idx_t = torch.nonzero(lm_flat != -1).squeeze(1)
+        labelled = image_label == 1
+        n_reg_all = sequence_output_v.size(1)                       # regions incl. the global row 0
+        idx_r = torch.nonzero(labelled.reshape(-1)).squeeze(1)      # index into [B, n_reg_all - 1]
+        if idx_t.numel() == 0 or idx_r.numel() == 0:
+            return None
+        per = n_reg_all - 1
+        idx_v = idx_r + torch.div(idx_r, per, rounding_mode="floor") + 1   # same rows inside [B, n_reg_all]
+
+        pooled_output = _dropout(_fuse_pooled(cls.fusion_method, pooled_output_t, pooled_output_v), cls.dropout)
+        seq_relationship_score = F.linear(pooled_output, cls.bi_seq_relationship.weight,
+                                          cls.bi_seq_relationship.bias)
+        next_sentence_loss = self.loss_fct(seq_relationship_score.view(-1, 2), next_sentence_label.view(-1))
+
+        rows_t = sequence_output_t.reshape(-1, sequence_output_t.size(-1)).index_select(0, idx_t)
+        masked_lm_loss = self.loss_fct(cls.predictions(rows_t), lm_flat.index_select(0, idx_t))
+
+        rows_v = sequence_output_v.reshape(-1, sequence_output_v.size(-1)).index_select(0, idx_v)
+        scores_v = cls.imagePredictions(rows_v)
+        target = image_target.reshape(-1, image_target.size(-1)).index_select(0, idx_r)
+        if self.visual_target == 1:
+            masked_img_loss = torch.sum(self.vis_criterion(scores_v, target)) / max(
+                torch.sum(labelled.unsqueeze(2).expand(-1, -1, image_target.size(-1))), 1)
+        else:
+            masked_img_loss = torch.sum(self.vis_criterion(TF.log_softmax(scores_v, dim=1), target)) / max(
+                torch.sum(labelled), 0)
         return masked_lm_loss.unsqueeze(0), masked_img_loss.unsqueeze(0), next_sentence_loss.unsqueeze(0)
 
     def _nce_region_loss(self, input_ids, prediction_scores_v, image_target, labelled):
