@@ -225,6 +225,16 @@ def main():
                 + 2 * cfg["bi_hidden_size"] * 2
         sps = world * B * args.steps / elapsed
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic, traffic_note = None, "not measured"
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.isfile(tpath):
+            # HBM bytes per launch cannot be read from inside the process; this is the rocprofv3 PMC
+            # measurement (FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction) of the dominant forward
+            # GEMM shape, committed under profiles/
+            t0 = json.load(open(tpath))["launches"][0]
+            traffic = t0["hbm_bytes_corrected"]
+            traffic_note = "rocprofv3 PMC, %s M=%d N=%d K=%d: %.0f MB per launch vs %.0f MB algorithmic (profiles/r01_gemm_traffic.json)" % (
+                t0["kernel"], t0["M"], t0["N"], t0["K"], traffic / 1e6, t0["algorithmic_bytes"] / 1e6)
         line = {
             "metric": "samples/sec (36 regions, 36 tokens) ViLBERT-base 6L/6C %s" %
                       ("forward" if args.mode == "fwd" else "fwd+bwd"),
@@ -246,7 +256,8 @@ def main():
             "model_frac_of_fp32_mfma_peak": round(sps / world * mult * exec_f / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "what": "all GEMM launches of %d extra step(s) (fwd%s), algorithmic 2MNK FLOPs / "
                                  "sum of HIP-event durations" % (prof_steps, "" if args.mode == "fwd" else " + dgrad + wgrad"),
                          "launches_per_step": gemm_launches // prof_steps,

@@ -93,17 +93,20 @@ typedef struct {
 int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args* a);
 
 /* ------------------------------------------------------------------------------------------
- * vb_linear_bwd_weight:  dW[n,K] (+)= dY[:, 0:n]^T . X[M,K]   and   dbias[n] (+)= colsum(dY[:, 0:n])
- * Gradient of nn.Linear w.r.t. weight and bias of ONE segment (dY points at the segment's first
- * column, ldy is the full row stride). The contraction over the M rows is split over workgroups and
- * combined with fp32 atomics. dbias may be NULL. accumulate == 0 zero-fills dW / dbias first.
+ * vb_linear_bwd_weight:  dW[s][seg_n,K] (+)= dY[:, s*seg_n:(s+1)*seg_n]^T . X[M,K]
+ *                        dbias[s][seg_n] (+)= column sums of the same slice of dY
+ * Gradient of nn.Linear w.r.t. weight and bias of the nseg stacked segments (dY is [M, nseg*seg_n]
+ * with row stride ldy). The contraction over the M rows is split over workgroups and combined with
+ * fp32 atomics; the bias gradient is fused into the same launch. dbias[s] may be NULL.
+ * accumulate == 0 zero-fills dW / dbias first.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-    int32_t M, K, n;
+    int32_t M, K;
+    int32_t nseg, seg_n;
     const float* dY;           int64_t ldy;
     const float* X;            int64_t ldx;
-    float* dW;                 int64_t ldw;
-    float* dbias;
+    float* dW[VB_MAX_SEGMENTS]; int64_t ldw;
+    float* dbias[VB_MAX_SEGMENTS];
     int32_t accumulate;
 } vb_linear_bwd_weight_args;
 

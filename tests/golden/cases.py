@@ -31,6 +31,17 @@ CASES = {
     "tiny_pretraining_scores": dict(kind="pretraining", cfg=lambda: synth.tiny_config(), batch=4, n_tok=9, n_reg=8),
     "tiny_pretraining_losses": dict(kind="pretraining", cfg=lambda: synth.tiny_config(), batch=4, n_tok=9, n_reg=8,
                                     labels=True),
+    # inference variants of the same path
+    # eval_retrieval.py:220,263-311: fast_mode, ONE caption against N images (text batch 1 is expanded
+    # inside the encoder, reference vilbert.py:1042-1053)
+    "tiny_fast_mode_1xN": dict(kind="vltasks", cfg=lambda: synth.tiny_config(fast_mode=True), batch=5, n_tok=8,
+                               n_reg=6, text_batch=1),
+    # in_batch_pairs: every caption against every image, batch becomes B*B (:1008-1040)
+    # (pre-training wrapper: VILBertForVLTasks itself cannot run this mode in the reference - its
+    # vision_logit mask is still batch B, vilbert.py:1692-1694)
+    "tiny_in_batch_pairs": dict(kind="pretraining", cfg=lambda: synth.tiny_config(in_batch_pairs=True), batch=3,
+                                n_tok=7, n_reg=5),
+    "tiny_roberta": dict(kind="vltasks", cfg=lambda: synth.tiny_config(model="roberta"), batch=2, n_tok=6, n_reg=4),
     # BASELINE.json configs[0]: bert_base_2layer_2conect.json, batch 8, 36 regions, 20 tokens
     "base_2l2c_b8": dict(kind="vltasks", cfg=lambda: synth.load_config("bert_base_2layer_2conect.json"),
                          batch=8, n_tok=20, n_reg=36,
@@ -48,6 +59,11 @@ def case_inputs(case):
     cfg = c["cfg"]()
     x = synth.make_inputs(cfg, c["batch"], c["n_tok"], c["n_reg"], with_labels=c.get("labels", False),
                           task_id=c.get("task_id"))
+    if c.get("text_batch"):  # one caption for the whole image batch
+        tb = c["text_batch"]
+        for k in ("input_ids", "token_type_ids", "attention_mask"):
+            x[k] = x[k][:tb].contiguous()
+        x["co_attention_mask"] = x["co_attention_mask"][:tb].contiguous()
     sd = synth.make_state_dict(cfg, c["kind"])
     return cfg, sd, x
 

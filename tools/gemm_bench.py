@@ -35,7 +35,7 @@ def main():
     dev = "cuda:0"
     if os.environ.get("GEMM_BENCH_QUICK"):
         FWD = [(M, 3072, 768, 1), (M, 30522, 768, 1)]
-    print("VB_GEMM_BK =", os.environ.get("VB_GEMM_BK", "default"))
+    print("VB_GEMM_HYBRID =", os.environ.get("VB_GEMM_HYBRID", "default(1)"), "VB_GEMM_FLAGS =", os.environ.get("VB_GEMM_FLAGS", "0"))
     tot_f = tot_t = 0.0
     for (m, n, k, nseg) in FWD:
         x = torch.randn(m, k, device=dev)

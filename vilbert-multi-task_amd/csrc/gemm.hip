@@ -5,17 +5,23 @@
 //   dgrad    (NN)  dX[M,K'] = dY[M,N'] . W[N',K']    A k-contiguous,  B j-contiguous
 //   wgrad    (TN)  dW[N',K'] = dY[M,N']^T . X[M,K']  A i-contiguous,  B j-contiguous
 //
-// Block = 256 threads = 4 waves (one per SIMD), block tile 128x128, K step 32, each wave owns a
-// 64x64 sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs). LDS is double buffered
-// (2 x 36 KiB -> two blocks per CU, i.e. two waves per SIMD so one block's barrier / epilogue is
-// covered by the other's MFMAs). Global -> register -> LDS staging: the loads for K tile t+1 are
-// issued before the 64 MFMAs (4096 matrix-pipe cycles) of tile t and written to the other LDS
-// buffer after them; one barrier per K tile.
+// Block = 256 threads = 4 waves (one per SIMD) in a 2x2 arrangement. Two tile shapes live in the same
+// kernel: BIG 128x128 (each wave 2x2 MFMA tiles of 32x32, 64 accumulator VGPRs) and SMALL 64x64 (each
+// wave one 32x32 tile). The matrix pipe of a SIMD is the bottleneck resource, so what matters is the
+// number of MFMA tiles queued per CU: with T big tiles over 256 CUs the last of ceil(T/256) rounds is
+// mostly empty for the model's shapes (432 / 576 / 592 tiles at batch 256). The launch therefore runs
+// floor(T/256) full rounds as big tiles and re-cuts the leftover big tiles into 4 small tiles each
+// (when that shortens the tail), which the dispatcher spreads over all CUs ("hybrid tail").
+//
+// K step 16, LDS double buffered: 2 x (A + B) x 128 x 20 floats = 40 KiB -> 3-4 blocks per CU, so
+// one block's barrier / prologue / epilogue is covered by the MFMAs of the others. Global -> register
+// -> LDS staging: the loads for K tile t+1 are issued before the MFMAs of tile t and written to the
+// other LDS buffer after them; one barrier per K tile.
 //
 // LDS layouts (floats):
-//   k-contiguous operand: [128 rows][36]  (32 + 4 pad): 16-lane ds_read_b128 groups hit 16
-//       distinct 16-B slots (row stride 36 dwords = 9 slots, odd) -> conflict free.
-//   row-contiguous operand: [32 k][132]: ds_read_b32, lanes = consecutive rows -> conflict free.
+//   k-contiguous operand: [rows][20]  (16 + 4 pad; 5 16-byte slots per row, odd): the 16-lane
+//       ds_read_b128 groups fall on 16 distinct slots -> conflict free.
+//   row-contiguous operand: [16 k][rows + 4]: ds_read_b32, lanes = consecutive rows -> conflict free.
 // MFMA operand convention (32x32x2): lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31].
 // The contraction order inside a K step is permuted (lane half `hi` owns k = 8c + 4hi + e) so that
 // a k-contiguous operand is fetched with one ds_read_b128 per four MFMAs; A and B use the same
@@ -27,41 +33,42 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int RC_LD = 132;   // row-contiguous LDS row stride ([BK][132])
+constexpr int BK = 16;
+constexpr int KC_LD = BK + 4;
+constexpr int OPER_SZ = 128 * KC_LD;         // 2560 floats >= 16 * 132 (row-contiguous big tile)
+constexpr int STAGE_SZ = 2 * OPER_SZ;        // A + B
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_SZ * 4;  // 40,960 B
 
-// K-step dependent geometry. k-contiguous LDS rows hold BK + 4 floats: (BK + 4) / 4 is odd for
-// BK = 16 / 32, so the 16-lane ds_read_b128 groups fall on 16 distinct 16-byte slots (conflict free).
-template <int BK> struct Geo {
-    static constexpr int KC_LD = BK + 4;
-    static constexpr int OPER_SZ = 128 * KC_LD;      // >= BK * RC_LD
-    static constexpr int STAGE_SZ = 2 * OPER_SZ;     // A + B
-    static constexpr int LDS_BYTES = 2 * STAGE_SZ * 4;  // double buffered: 73,728 B (BK 32), 40,960 B (BK 16)
-    static constexpr int NLD = BK / 8;               // float4 loads per thread per operand tile
-    static constexpr int KQ = BK / 4;                // float4 per k-contiguous row
-};
+enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC };
 
 struct GemmP {
     int M, N, K;
     const float* A; long lda;
-    const float* B[VB_MAX_SEGMENTS]; long ldb; int bseg;
+    const float* B[VB_MAX_SEGMENTS]; long ldb; int bseg;   // B row segments (stacked weights)
     const float* bias[VB_MAX_SEGMENTS];
-    float* C; long ldc;
+    float* C[VB_MAX_SEGMENTS]; long ldc; int cseg;          // C row segments (wgrad of stacked weights)
+    float* colsum[VB_MAX_SEGMENTS];  // row-contiguous A only: colsum[i] += sum_k A[i][k] (bias gradient)
     const float* R; long ldr;
     float* P; long ldp;
     int act;
     int accumulate;       // C += result
-    int tiles_m, tiles_n;
+    int tiles_n;          // big-tile grid columns
+    int n_big, n_small;   // blocks [0, n_big): big tiles; [n_big, n_big + n_small): small tiles
     int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
-    float* colsum;        // row-contiguous A only: colsum[i] += sum_k A[i][k] (bias gradient), may be null
-    int epi;              // EPI_* fast path of interior tiles (EPI_GENERIC = none)
+    int epi;              // EPI_* fast path of interior tiles
     int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
 };
 
-// Staging of one 128 x 32 operand tile into registers (4 float4 per thread).
-// k-contiguous operand (global [rows][ld]): thread t owns rows (t >> 3) + 32 it, it = 0..3, and the
-// four k values 4 (t & 7) .. +3 of every K tile, so the row base pointers are computed once per
-// block (this is also where a row is mapped to its weight segment).
+// XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).
+__device__ __forceinline__ int xcd_swizzle(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Staging of one R x 16 operand tile into registers (R / 64 float4 per thread).
+// k-contiguous operand (global [rows][ld]): thread t owns rows (t >> 2) + 64 it and the four k values
+// 4 (t & 3) .. +3 of every K tile, so the row base pointers are computed once per block (this is also
+// where a row is mapped to its weight segment).
 template <bool VEC, int NLD>
 __device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[NLD], const float* const (&rowp)[NLD], int k, int K) {
 #pragma unroll
@@ -81,16 +88,15 @@ __device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[NLD], const float* con
     }
 }
 
-// row-contiguous operand (global [k][ld], rows contiguous): thread t owns k = (t >> 5) + 8 it and the
-// four rows row0 + 4 (t & 31) .. +3.
-template <bool VEC, int NLD>
-__device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[NLD], const float* __restrict__ base, long ld,
+// row-contiguous operand (global [k][ld], rows contiguous): R / 4 float4 per k row.
+template <bool VEC, int R>
+__device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[R / 64], const float* __restrict__ base, long ld,
                                              int row0, int nrows, int k0, int K, int tid) {
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
+    for (int it = 0; it < R / 64; ++it) {
         const int f = tid + 256 * it;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int k = k0 + (f >> 5), row = row0 + (f & 31) * 4;
+        const int k = k0 + f / (R / 4), row = row0 + (f % (R / 4)) * 4;
         if (k < K) {
             const float* g = base + (long)k * ld + row;
             if (VEC) {
@@ -105,36 +111,32 @@ __device__ __forceinline__ void load_tile_rc(f32x4 (&reg)[NLD], const float* __r
     }
 }
 
-template <bool KC, int BK>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&reg)[BK / 8], int tid) {
-    constexpr int KQ = BK / 4;
+template <bool KC, int R>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&reg)[R / 64], int tid) {
 #pragma unroll
-    for (int it = 0; it < BK / 8; ++it) {
+    for (int it = 0; it < R / 64; ++it) {
         const int f = tid + 256 * it;
-        const int off = KC ? (f / KQ) * (BK + 4) + (f % KQ) * 4 : (f >> 5) * RC_LD + (f & 31) * 4;
+        const int off = KC ? (f >> 2) * KC_LD + (f & 3) * 4 : (f / (R / 4)) * (R + 4) + (f % (R / 4)) * 4;
         *reinterpret_cast<f32x4*>(s + off) = reg[it];
     }
 }
 
-enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC };
-
 // Branch-free epilogue of a full interior tile. MODE: STORE c = v; GELU c = gelu(v); RES c = v + R;
 // PRE_GELU P = v, c = gelu(v); ACCUM c += v; ATOMIC atomicAdd(c, v)   with v = acc + bias.
-template <int MODE>
-__device__ __forceinline__ void epilogue_full(const GemmP& p, const f32x16 (&acc)[2][2], const float (&bv)[2],
-                                              int row0, int col0) {
-    float* __restrict__ cbase = p.C + (long)row0 * p.ldc + col0;
+template <int MODE, int TM, int TN>
+__device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict__ cptr, const f32x16 (&acc)[TM][TN],
+                                              const float (&bv)[TN], int row0, int col0) {
     const float* __restrict__ rbase = MODE == EPI_RES ? p.R + (long)row0 * p.ldr + col0 : nullptr;
     float* __restrict__ pbase = MODE == EPI_PRE_GELU ? p.P + (long)row0 * p.ldp + col0 : nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 float v = acc[i][j][r] + bv[j];
-                float* c = cbase + (long)dr * p.ldc + j * 32;
+                float* c = cptr + (long)dr * p.ldc + j * 32;
                 if (MODE == EPI_PRE_GELU) pbase[(long)dr * p.ldp + j * 32] = v;
                 if (MODE == EPI_GELU || MODE == EPI_PRE_GELU) v = gelu_erf(v);
                 if (MODE == EPI_RES) v += rbase[(long)dr * p.ldr + j * 32];
@@ -146,25 +148,15 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, const f32x16 (&acc
     }
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int BK>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    using G = Geo<BK>;
-    constexpr int KC_LD = G::KC_LD, OPER_SZ = G::OPER_SZ, STAGE_SZ = G::STAGE_SZ, NLD = G::NLD, KQ = G::KQ;
+// One (64 TM) x (64 TN) output tile at (m0, n0).
+template <int TM, int TN, bool A_KC, bool B_KC, bool VEC>
+__device__ __forceinline__ void gemm_tile(const GemmP& p, float* __restrict__ smem, const int m0, const int n0) {
+    constexpr int RA = 64 * TM, RB = 64 * TN;   // operand tile rows
+    constexpr int NA = RA / 64, NB = RB / 64;   // float4 per thread per operand tile
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap of the linear block id (guide T1).
-    const int nb = p.tiles_m * p.tiles_n;
-    int logical;
-    {
-        const int b = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int m0 = (logical / p.tiles_n) * BM;
-    const int n0 = (logical % p.tiles_n) * BN;
 
     const int kt_total = (p.K + BK - 1) / BK;
     const int kt_begin = blockIdx.y * p.ktiles_per_split;
@@ -173,49 +165,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
     // Row base pointers of the k-contiguous operands. B rows (= output columns) are mapped to their
     // weight segment here: the segments are stacked along N (q | k | v projections in one launch).
-    const float* arow[NLD];
-    const float* brow[NLD];
-    const int kq = (tid % KQ) * 4;
+    const float* arow[NA];
+    const float* brow[NB];
+    const int kq = (tid & 3) * 4;
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
-        arow[it] = nullptr;
+    for (int it = 0; it < NA; ++it) {
+        const int r = (tid >> 2) + 64 * it;
+        arow[it] = (A_KC && m0 + r < p.M) ? p.A + (long)(m0 + r) * p.lda : nullptr;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        const int n = n0 + (tid >> 2) + 64 * it;
         brow[it] = nullptr;
-        const int r = tid / KQ + (256 / KQ) * it;
-        if (A_KC && m0 + r < p.M) arow[it] = p.A + (long)(m0 + r) * p.lda;
-        if (B_KC && n0 + r < p.N) {
-            const int n = n0 + r, sg = n / p.bseg;
+        if (B_KC && n < p.N) {
+            const int sg = n / p.bseg;
             brow[it] = p.B[sg] + (long)(n - sg * p.bseg) * p.ldb;
         }
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[NLD], rb[NLD];
+    f32x4 ra[NA], rb[NB];
     float csum = 0.f;
 
     auto load_ab = [&](int kt) {
         const int k0 = kt * BK;
-        if (A_KC) load_tile_kc<VEC, NLD>(ra, arow, k0 + kq, p.K);
-        else load_tile_rc<VEC, NLD>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
+        if (A_KC) load_tile_kc<VEC, NA>(ra, arow, k0 + kq, p.K);
+        else load_tile_rc<VEC, RA>(ra, p.A, p.lda, m0, p.M, k0, p.K, tid);
         if (B_KC) {
-            load_tile_kc<VEC, NLD>(rb, brow, k0 + kq, p.K);
+            load_tile_kc<VEC, NB>(rb, brow, k0 + kq, p.K);
         } else {
             // segments stacked along K (dgrad through stacked weights); bseg is a multiple of BK
             const int sg = k0 / p.bseg;
-            load_tile_rc<VEC, NLD>(rb, p.B[sg], p.ldb, n0, p.N, k0 - sg * p.bseg, min(p.bseg, p.K - sg * p.bseg), tid);
+            load_tile_rc<VEC, RB>(rb, p.B[sg], p.ldb, n0, p.N, k0 - sg * p.bseg, min(p.bseg, p.K - sg * p.bseg), tid);
         }
     };
 
     load_ab(kt_begin);
-    store_tile<A_KC, BK>(smem, ra, tid);
-    store_tile<B_KC, BK>(smem + OPER_SZ, rb, tid);
+    store_tile<A_KC, RA>(smem, ra, tid);
+    store_tile<B_KC, RB>(smem + OPER_SZ, rb, tid);
     __syncthreads();
+
+    const bool want_colsum = !A_KC && n0 == 0 && tid < RA && p.colsum[0] != nullptr;
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
@@ -227,63 +224,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
-            f32x4 af[2], bf[2];
+            f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TM; ++t) {
                 if (A_KC) {
                     af[t] = *reinterpret_cast<const f32x4*>(
-                        sA + (wm * 64 + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                        sA + (wm * 32 * TM + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        af[t][e] = sA[(kc * 8 + hi * 4 + e) * RC_LD + wm * 64 + t * 32 + l31];
+                        af[t][e] = sA[(kc * 8 + hi * 4 + e) * (RA + 4) + wm * 32 * TM + t * 32 + l31];
                 }
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
                 if (B_KC) {
                     bf[t] = *reinterpret_cast<const f32x4*>(
-                        sB + (wn * 64 + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                        sB + (wn * 32 * TN + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        bf[t][e] = sB[(kc * 8 + hi * 4 + e) * RC_LD + wn * 64 + t * 32 + l31];
+                        bf[t][e] = sB[(kc * 8 + hi * 4 + e) * (RB + 4) + wn * 32 * TN + t * 32 + l31];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
                                                                         acc[i][j], 0, 0, 0);
         }
-
         if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
-        if (!A_KC && p.colsum != nullptr && n0 == 0 && tid < BM) {
+
+        if (want_colsum) {
             // bias gradient fused into wgrad: A = dY^T, so the sum over this K tile of row i = tid
 #pragma unroll
-            for (int kk = 0; kk < BK; ++kk) csum += sA[kk * RC_LD + tid];
+            for (int kk = 0; kk < BK; ++kk) csum += sA[kk * (RA + 4) + tid];
         }
 
         if (more) {
             float* dA = smem + (cur ^ 1) * STAGE_SZ;
-            store_tile<A_KC, BK>(dA, ra, tid);
-            store_tile<B_KC, BK>(dA + OPER_SZ, rb, tid);
+            store_tile<A_KC, RA>(dA, ra, tid);
+            store_tile<B_KC, RB>(dA + OPER_SZ, rb, tid);
         }
         __syncthreads();
     }
 
-    if (!A_KC && p.colsum != nullptr && n0 == 0 && tid < BM && m0 + tid < p.M)
-        unsafeAtomicAdd(p.colsum + m0 + tid, csum);
+    // C row segment of this tile (tiles never straddle segments: cseg is a multiple of the tile rows)
+    const int cs = m0 / p.cseg;
+    const int mloc = m0 - cs * p.cseg;  // row of the tile inside its segment
+    if (want_colsum && mloc + tid < p.cseg && m0 + tid < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + tid, csum);
 
     // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     // Interior tiles with one of the common epilogues take a branch-free specialised path (the generic
     // predicated loop costs ~2k VALU instructions per wave, during which the matrix pipe starves when
     // the co-resident blocks reach their epilogues together).
     const bool lead = blockIdx.y == 0;  // bias / residual are added by one split only
-    float bv[2];
+    float bv[TN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + j * 32 + l31;
         bv[j] = 0.f;
         if (col < p.N && lead) {
             const int sg = B_KC ? col / p.bseg : 0;  // bias follows the N segmentation of a k-contiguous B
@@ -291,35 +293,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
             if (bp != nullptr) bv[j] = bp[col - sg * p.bseg * (B_KC ? 1 : 0)];
         }
     }
-    const int row0 = m0 + wm * 64 + 4 * hi, col0 = n0 + wn * 64 + l31;
-    if (m0 + BM <= p.M && n0 + BN <= p.N && p.epi != EPI_GENERIC) {
+    const int row0 = m0 + wm * 32 * TM + 4 * hi, col0 = n0 + wn * 32 * TN + l31;
+    float* cptr = p.C[cs] + (long)(row0 - cs * p.cseg) * p.ldc + col0;
+    if (m0 + RA <= p.M && n0 + RB <= p.N && p.epi != EPI_GENERIC) {
         switch (p.epi) {
-            case EPI_STORE: epilogue_full<EPI_STORE>(p, acc, bv, row0, col0); break;
-            case EPI_GELU: epilogue_full<EPI_GELU>(p, acc, bv, row0, col0); break;
-            case EPI_RES: epilogue_full<EPI_RES>(p, acc, bv, row0, col0); break;
-            case EPI_PRE_GELU: epilogue_full<EPI_PRE_GELU>(p, acc, bv, row0, col0); break;
-            case EPI_ACCUM: epilogue_full<EPI_ACCUM>(p, acc, bv, row0, col0); break;
-            default: epilogue_full<EPI_ATOMIC>(p, acc, bv, row0, col0); break;
+            case EPI_STORE: epilogue_full<EPI_STORE, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_GELU: epilogue_full<EPI_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_RES: epilogue_full<EPI_RES, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_PRE_GELU: epilogue_full<EPI_PRE_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_ACCUM: epilogue_full<EPI_ACCUM, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            default: epilogue_full<EPI_ATOMIC, TM, TN>(p, cptr, acc, bv, row0, col0); break;
         }
         return;
     }
     const bool split = gridDim.y > 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
         const int col = col0 + j * 32;
         if (col >= p.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const int row = row0 + dr;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bv[j];
                 if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
                 if (p.act == VB_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
                 if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
-                float* c = p.C + (long)row * p.ldc + col;
+                float* c = cptr + (long)dr * p.ldc + j * 32;
                 if (split) unsafeAtomicAdd(c, v);
                 else if (p.accumulate) *c += v;
                 else *c = v;
@@ -328,43 +332,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
 }
 
-constexpr int BK_DEFAULT = 16;
-
-inline int gemm_bk() {
-    // K step of the GEMM kernels; VB_GEMM_BK=32 selects the 72 KiB double buffer (tuning knob).
-    static int bk = [] {
-        const char* e = getenv("VB_GEMM_BK");
-        const int v = e ? atoi(e) : BK_DEFAULT;
-        return v == 32 ? 32 : 16;
-    }();
-    return bk;
+template <bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < p.n_big) {
+        const int t = xcd_swizzle(b, p.n_big);
+        gemm_tile<2, 2, A_KC, B_KC, VEC>(p, smem, (t / p.tiles_n) * 128, (t % p.tiles_n) * 128);
+    } else {
+        // leftover big tiles, re-cut into four 64x64 tiles each
+        const int s = xcd_swizzle(b - p.n_big, p.n_small);
+        const int t = p.n_big + (s >> 2);
+        const int m0 = (t / p.tiles_n) * 128 + ((s >> 1) & 1) * 64;
+        const int n0 = (t % p.tiles_n) * 128 + (s & 1) * 64;
+        if (m0 >= p.M || n0 >= p.N) return;
+        gemm_tile<1, 1, A_KC, B_KC, VEC>(p, smem, m0, n0);
+    }
 }
 
-template <bool A_KC, bool B_KC, bool VEC, int BK>
-int launch_gemm_bk(hipStream_t st, const GemmP& p, int splits) {
-    dim3 grid(p.tiles_m * p.tiles_n, splits), block(256);
-    auto k = gemm_f32_kernel<A_KC, B_KC, VEC, BK>;
-    static bool attr_done = false;  // > 64 KiB of dynamic LDS needs the attribute once per kernel
-    if (Geo<BK>::LDS_BYTES > 65536 && !attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Geo<BK>::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k, grid, block, Geo<BK>::LDS_BYTES, st, p);
-    VB_LAUNCH_CHECK();
-    return 0;
+// Tile plan: full rounds of 256 big tiles, leftover as small tiles when that shortens the tail.
+void plan_tiles(GemmP& p, int splits) {
+    const int tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + 127) / 128;
+    const int total = tiles_m * p.tiles_n;
+    static const int hybrid = [] { const char* e = getenv("VB_GEMM_HYBRID"); return e ? atoi(e) : 1; }();
+    const int left = total % 256;
+    // 4 * left small tiles cost ceil(4 left / 256) quarter-rounds vs one full big round (= 4)
+    const bool recut = hybrid && splits == 1 && left > 0 && (4 * left + 255) / 256 < 4 && (p.cseg % 64) == 0;
+    p.n_big = recut ? total - left : total;
+    p.n_small = recut ? 4 * left : 0;
 }
 
 template <bool A_KC, bool B_KC>
 int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
     static const int flags = [] { const char* e = getenv("VB_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
     p.flags = flags;
-    if (gemm_bk() == 32)
-        return vec ? launch_gemm_bk<A_KC, B_KC, true, 32>(st, p, splits)
-                   : launch_gemm_bk<A_KC, B_KC, false, 32>(st, p, splits);
-    return vec ? launch_gemm_bk<A_KC, B_KC, true, 16>(st, p, splits)
-               : launch_gemm_bk<A_KC, B_KC, false, 16>(st, p, splits);
+    plan_tiles(p, splits);
+    dim3 grid(p.n_big + p.n_small, splits), block(256);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, GEMM_LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, GEMM_LDS_BYTES, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -385,16 +393,14 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
         p.bias[s] = a->bias[s];
         vec = vec && vb_aligned16(a->W[s]);
     }
-    p.C = a->C; p.ldc = a->ldc;
+    p.C[0] = a->C; p.ldc = a->ldc; p.cseg = (p.M + 127) / 128 * 128;
     p.R = a->residual; p.ldr = a->ldr;
     p.P = a->preact; p.ldp = a->ldp;
     p.act = a->act; p.accumulate = 0;
     if (a->act == VB_ACT_NONE && a->preact == nullptr) p.epi = a->residual != nullptr ? EPI_RES : EPI_STORE;
     else if (a->act == VB_ACT_GELU && a->residual == nullptr) p.epi = a->preact != nullptr ? EPI_PRE_GELU : EPI_GELU;
     else p.epi = EPI_GENERIC;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    p.ktiles_per_split = (p.K + gemm_bk() - 1) / gemm_bk();
+    p.ktiles_per_split = (p.K + BK - 1) / BK;
     return launch_gemm<true, true>(static_cast<hipStream_t>(stream), p, vec, 1);
 }
 
@@ -406,7 +412,6 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
     hipStream_t st = static_cast<hipStream_t>(stream);
     // a K tile of the contraction (over out-features) must not straddle two weight segments; otherwise
     // run one launch per segment, accumulating.
-    const int BK = gemm_bk();
     const bool fused = a->nseg == 1 || (a->seg_n % BK) == 0;
     const int launches = fused ? 1 : a->nseg;
     for (int l = 0; l < launches; ++l) {
@@ -423,51 +428,78 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
             p.B[s] = w;
             vec = vec && vb_aligned16(w);
         }
-        p.C = a->dX; p.ldc = a->ldx;
+        p.C[0] = a->dX; p.ldc = a->ldx; p.cseg = (p.M + 127) / 128 * 128;
         p.act = VB_ACT_NONE;
         p.accumulate = (a->accumulate || l > 0) ? 1 : 0;
         p.epi = p.accumulate ? EPI_ACCUM : EPI_STORE;
-        p.tiles_m = (p.M + BM - 1) / BM;
-        p.tiles_n = (p.N + BN - 1) / BN;
         p.ktiles_per_split = (p.K + BK - 1) / BK;
         if (int e = launch_gemm<true, false>(st, p, vec, 1)) return e;
     }
     return 0;
 }
 
-// dW[n,K] (+)= dY[:, :n]^T . X[M,K] and dbias[n] (+)= column sums of dY   - nn.Linear backward w.r.t.
-// weight and bias. The contraction runs over the M rows: split over gridDim.y with fp32 atomics.
+// dW_s[seg_n,K] (+)= dY[:, s]^T . X[M,K] and dbias_s[seg_n] (+)= column sums of dY[:, s] - nn.Linear
+// backward w.r.t. weight and bias of the stacked segments. The contraction runs over the M rows: split
+// over gridDim.y with fp32 atomics. Segments whose size is a multiple of 128 share one launch.
 extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_args* a) {
-    if (a == nullptr || a->dY == nullptr || a->X == nullptr || a->dW == nullptr) return VB_E_BADARG;
-    if (a->M <= 0 || a->K <= 0 || a->n <= 0) return VB_E_BADARG;
+    if (a == nullptr || a->dY == nullptr || a->X == nullptr) return VB_E_BADARG;
+    if (a->M <= 0 || a->K <= 0 || a->seg_n <= 0) return VB_E_BADARG;
+    if (a->nseg < 1 || a->nseg > VB_MAX_SEGMENTS) return VB_E_SEGMENT;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!a->accumulate) {
-        hipError_t e = hipMemset2DAsync(a->dW, a->ldw * sizeof(float), 0, (size_t)a->K * sizeof(float), a->n, st);
-        if (e != hipSuccess) return (int)e;
-        if (a->dbias != nullptr) {
-            e = hipMemsetAsync(a->dbias, 0, (size_t)a->n * sizeof(float), st);
+    for (int s = 0; s < a->nseg; ++s) {
+        if (a->dW[s] == nullptr) return VB_E_SEGMENT;
+        if (!a->accumulate) {
+            hipError_t e = hipMemset2DAsync(a->dW[s], a->ldw * sizeof(float), 0, (size_t)a->K * sizeof(float),
+                                            a->seg_n, st);
             if (e != hipSuccess) return (int)e;
+            if (a->dbias[s] != nullptr) {
+                e = hipMemsetAsync(a->dbias[s], 0, (size_t)a->seg_n * sizeof(float), st);
+                if (e != hipSuccess) return (int)e;
+            }
         }
     }
-    GemmP p{};
-    p.M = a->n; p.N = a->K; p.K = a->M;
-    p.A = a->dY; p.lda = a->ldy;
-    p.B[0] = a->X; p.ldb = a->ldx; p.bseg = a->M;
-    p.C = a->dW; p.ldc = a->ldw;
-    p.act = VB_ACT_NONE; p.accumulate = 1;
-    p.colsum = a->dbias;
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    const int BK = gemm_bk();
-    const int kt_total = (p.K + BK - 1) / BK;
-    const int tiles = p.tiles_m * p.tiles_n;
-    int splits = (1024 + tiles - 1) / tiles;  // aim at ~4 blocks per CU
-    if (splits > kt_total) splits = kt_total;
-    if (splits < 1) splits = 1;
-    p.ktiles_per_split = (kt_total + splits - 1) / splits;
-    splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
-    const bool vec = (a->n % 4 == 0) && (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) &&
-                     vb_aligned16(a->dY) && vb_aligned16(a->X);
-    p.epi = splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
-    return launch_gemm<false, false>(st, p, vec, splits);
+    bool same_bias = true;  // the fused launch needs bias gradients for all segments or for none
+    for (int s = 1; s < a->nseg; ++s) same_bias = same_bias && ((a->dbias[s] != nullptr) == (a->dbias[0] != nullptr));
+    const bool fused = a->nseg == 1 || ((a->seg_n % 128) == 0 && same_bias);
+    const int launches = fused ? 1 : a->nseg;
+    const int segs = fused ? a->nseg : 1;
+    for (int l = 0; l < launches; ++l) {
+        GemmP p{};
+        p.M = segs * a->seg_n; p.N = a->K; p.K = a->M;
+        p.A = a->dY + (long)l * a->seg_n; p.lda = a->ldy;
+        p.B[0] = a->X; p.ldb = a->ldx; p.bseg = a->M;
+        p.ldc = a->ldw;
+        p.cseg = segs == 1 ? (a->seg_n + 127) / 128 * 128 : a->seg_n;
+        for (int s = 0; s < segs; ++s) {
+            p.C[s] = a->dW[l + s];
+            p.colsum[s] = a->dbias[l + s];
+        }
+        p.act = VB_ACT_NONE; p.accumulate = 1;
+        const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+        const int kt_total = (p.K + BK - 1) / BK;
+        // Split count: tiles x splits workgroups should fill r whole "one block per CU" rounds of the 256
+        // CUs (all co-resident, so r = blocks per CU) WITHOUT spilling into a partial extra round.
+        // Measured: r = 4 beats fewer, longer blocks (one block per CU leaves the matrix pipe idle during
+        // every barrier / epilogue); take the largest r <= 4 that fills >= 93 % of its slots.
+        int splits = 1;
+        {
+            double best = -1.0;
+            for (int r = 4; r >= 2; --r) {
+                int s = (256 * r) / tiles;
+                if (s < 1) s = 1;
+                if (s > kt_total / 4) s = kt_total / 4 > 0 ? kt_total / 4 : 1;  // >= 4 K tiles per block
+                const int blocks = tiles * s;
+                const double fill = (double)blocks / (256.0 * ((blocks + 255) / 256));
+                if (fill > best + 1e-9) { best = fill; splits = s; }
+                if (fill >= 0.93) break;
+            }
+        }
+        p.ktiles_per_split = (kt_total + splits - 1) / splits;
+        splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
+        const bool vec = (a->seg_n % 4 == 0) && (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) &&
+                         vb_aligned16(p.A) && vb_aligned16(a->X);
+        p.epi = splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
+        if (int e = launch_gemm<false, false>(st, p, vec, splits)) return e;
+    }
+    return 0;
 }

@@ -383,14 +383,14 @@ __global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int 
     const int b = (int)(row / n_out), t_out = (int)(row % n_out);
     const bool is_task = task_ids != nullptr && t_out == 1;
     const int t = (task_ids != nullptr && t_out >= 2) ? t_out - 1 : t_out;
-    float *w = nullptr, *pp = nullptr, *ty = nullptr;
+    float* w = nullptr;
     if (is_task) {
         w = dtask + task_ids[b] * hidden;
     } else {
         const int64_t id = ids[(long)b * n_tok + t];
         w = id != 0 ? dword + id * hidden : nullptr;
-        pp = dpos + (long)t * hidden;
-        ty = dtype + seg[(long)b * n_tok + t] * hidden;
+        // position / token-type rows are shared by every sample (36 + 2 rows for 9216 tokens): they are
+        // reduced by pos_type_grad_kernel instead of 9216-way contended atomics
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -398,11 +398,41 @@ __global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int 
         if (col < hidden) {
             const f32x4 d = *reinterpret_cast<const f32x4*>(dx + row * hidden + col);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e)
                 if (w != nullptr) unsafeAtomicAdd(w + col + e, d[e]);
-                if (pp != nullptr) unsafeAtomicAdd(pp + col + e, d[e]);
-                if (ty != nullptr) unsafeAtomicAdd(ty + col + e, d[e]);
+        }
+    }
+}
+
+// dpos[t] += sum_b dx[b, t] and dtype[s] += sum over the tokens of type s: one block per token
+// position walks the batch (coalesced rows), so dpos needs no atomics and dtype one per position.
+__global__ __launch_bounds__(256) void pos_type_grad_kernel(int batch, int n_tok, int hidden,
+                                                            const int64_t* __restrict__ seg,
+                                                            const int64_t* __restrict__ task_ids,
+                                                            const float* __restrict__ dx,
+                                                            float* __restrict__ dpos, float* __restrict__ dtype) {
+    const int n_out = n_tok + (task_ids != nullptr ? 1 : 0);
+    const int t_out = blockIdx.x;
+    if (task_ids != nullptr && t_out == 1) return;  // the task-token row has no position / type
+    const int t = (task_ids != nullptr && t_out >= 2) ? t_out - 1 : t_out;
+    for (int col = threadIdx.x * 4; col < hidden; col += 256 * 4) {
+        f32x4 ap = {0.f, 0.f, 0.f, 0.f}, a0 = ap, a1 = ap;
+        for (int b = 0; b < batch; ++b) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dx + ((long)b * n_out + t_out) * hidden + col);
+            const int64_t ty = seg[(long)b * n_tok + t];
+            ap += d;
+            if (ty == 0) a0 += d;
+            else if (ty == 1) a1 += d;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dtype + ty * hidden + col + e, d[e]);
             }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsafeAtomicAdd(dpos + (long)t * hidden + col + e, ap[e]);
+            unsafeAtomicAdd(dtype + col + e, a0[e]);
+            unsafeAtomicAdd(dtype + hidden + col + e, a1[e]);
         }
     }
 }
@@ -453,6 +483,9 @@ extern "C" int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int
     VB_NV_DISPATCH(nv_for(hidden), hipLaunchKernelGGL((text_embed_scatter_kernel<NV>), grid, block, 0, st, batch,
                                                       n_tok, hidden, ids, seg, task_ids, dx, dword, dpos, dtype,
                                                       dtask));
+    VB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pos_type_grad_kernel, dim3((unsigned)(n_tok + (task_ids != nullptr ? 1 : 0))), dim3(256), 0,
+                       st, batch, n_tok, hidden, seg, task_ids, dx, dpos, dtype);
     VB_LAUNCH_CHECK();
     return 0;
 }

@@ -79,11 +79,12 @@ class LinearBwdInputArgs(ctypes.Structure):
 class LinearBwdWeightArgs(ctypes.Structure):
     """vb_linear_bwd_weight_args"""
     _fields_ = [
-        ("M", ctypes.c_int32), ("K", ctypes.c_int32), ("n", ctypes.c_int32),
+        ("M", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32),
         ("dY", _c_f32p), ("ldy", ctypes.c_int64),
         ("X", _c_f32p), ("ldx", ctypes.c_int64),
-        ("dW", _c_f32p), ("ldw", ctypes.c_int64),
-        ("dbias", _c_f32p),
+        ("dW", _c_f32p * VB_MAX_SEGMENTS), ("ldw", ctypes.c_int64),
+        ("dbias", _c_f32p * VB_MAX_SEGMENTS),
         ("accumulate", ctypes.c_int32),
     ]
 

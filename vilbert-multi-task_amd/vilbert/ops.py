@@ -122,26 +122,27 @@ def linear_bwd_input(dy, weights, in_features):
 
 
 def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
-    """Per segment: dW_s = dY[:, s]^T @ X and db_s = colsum(dY[:, s]). Returns (list dW, list db or None)."""
+    """Per segment: dW_s = dY[:, s]^T @ X and db_s = colsum(dY[:, s]) in one call.
+    Returns (list dW, list db-or-None)."""
     dy = _contig(dy)
     K = x.shape[-1]
     x2, ldx, _ = _row_view(x, K)
     M = x2.shape[0]
+    a = N.LinearBwdWeightArgs()
+    a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
+    a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), nseg * seg_n
+    a.X, a.ldx = N.dev_f32(x2, "linear input"), ldx
+    a.ldw, a.accumulate = K, 0
     dws, dbs = [], []
     for s in range(nseg):
         dw = torch.empty(seg_n, K, dtype=torch.float32, device=dy.device)
         db = torch.empty(seg_n, dtype=torch.float32, device=dy.device) if want_bias[s] else None
-        a = N.LinearBwdWeightArgs()
-        a.M, a.K, a.n = M, K, seg_n
-        a.dY, a.ldy = N.dev_f32(dy, "linear grad_output") + 4 * s * seg_n, nseg * seg_n
-        a.X, a.ldx = N.dev_f32(x2, "linear input"), ldx
-        a.dW, a.ldw = dw.data_ptr(), K
-        a.dbias = db.data_ptr() if db is not None else None
-        a.accumulate = 0
-        _timed(lambda: N.check(N.lib().vb_linear_bwd_weight(N.stream_ptr(), ctypes.byref(a)),
-                               "vb_linear_bwd_weight"), 2.0 * M * seg_n * K)
+        a.dW[s] = dw.data_ptr()
+        a.dbias[s] = db.data_ptr() if db is not None else None
         dws.append(dw)
         dbs.append(db)
+    _timed(lambda: N.check(N.lib().vb_linear_bwd_weight(N.stream_ptr(), ctypes.byref(a)), "vb_linear_bwd_weight"),
+           2.0 * M * nseg * seg_n * K)
     return dws, dbs
 
 
