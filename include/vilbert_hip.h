@@ -49,6 +49,14 @@ extern "C" {
 int vb_abi_version(void);
 const char* vb_error_string(int code);
 
+/* Arithmetic of every vb_linear_* GEMM: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products, the default),
+ * 3 = "bf16x6": each fp32 operand split exactly into three bf16 planes and the six largest partial
+ * products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (fp32-class result, ~1.2x faster),
+ * 2 = "bf16x3": two planes, three products (error ~2^-16 per product). Returns the previous mode; an
+ * unknown value only queries. Initial value from the environment variable VB_GEMM_MODE (f32 | bf16x6 |
+ * bf16x3). */
+int vb_set_gemm_mode(int planes);
+
 /* ------------------------------------------------------------------------------------------
  * vb_linear_fwd:  C[M, nseg*seg_n] = act( A[M,K] . W^T + bias ) (+ residual)
  *

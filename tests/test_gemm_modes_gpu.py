@@ -1,0 +1,74 @@
+"""The opt-in "split" GEMM modes (fp32 emulated on the bf16 matrix cores, csrc/gemm_split.hip) against the
+same fp64 references as the default exact-fp32 kernel, and model-level parity against the reference's
+golden vectors in bf16x6 mode (tolerance unchanged: fp32 1e-4)."""
+import pytest
+import torch
+
+import helpers
+from helpers import cases
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def mode(request):
+    from vilbert import _native
+    prev = _native.set_gemm_mode(request.param)
+    yield request.param
+    _native.set_gemm_mode(prev)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _check(got, want64, mode):
+    # bf16x6 keeps every partial product down to 2^-24: same tolerance as the fp32 kernel.
+    # bf16x3 drops terms of relative size 2^-16 per product.
+    tol = 3e-5 if mode == "bf16x6" else 6e-4
+    got = got.detach().cpu().double()
+    assert got.shape == want64.shape and torch.isfinite(got).all()
+    scale = max(1.0, want64.abs().max().item())
+    err = (got - want64).abs().max().item()
+    assert err <= tol * scale, "max err %.3e (scale %.3e, mode %s)" % (err, scale, mode)
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("M,N,K,nseg", [(128, 128, 16, 1), (300, 768, 768, 1), (180, 128, 192, 3), (100, 200, 52, 1),
+                                        (77, 64, 36, 3), (73, 96, 5, 1), (1, 1, 4, 1), (640, 1024, 2048, 1)])
+def test_split_modes_forward_backward(mode, M, N, K, nseg):
+    from vilbert import ops
+    x = _rand(M, K, seed=1)
+    ws = [_rand(N, K, seed=10 + i, scale=0.1) for i in range(nseg)]
+    bs = [_rand(N, seed=20 + i) for i in range(nseg)]
+    r = _rand(M, nseg * N, seed=3)
+    y, pre = ops.linear_fwd(x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs], act="gelu", residual=r.cuda(),
+                            want_preact=True)
+    pre64 = torch.cat([x.double() @ w.double().t() + b.double() for w, b in zip(ws, bs)], 1)
+    _check(pre, pre64, mode)
+    _check(y, torch.nn.functional.gelu(pre64) + r.double(), mode)
+    dy = _rand(M, nseg * N, seed=4)
+    _check(ops.linear_bwd_input(dy.cuda(), [w.cuda() for w in ws], K), dy.double() @ torch.cat(ws, 0).double(), mode)
+    dws, dbs = ops.linear_bwd_weight(dy.cuda(), x.cuda(), nseg, N, [True] * nseg)
+    for s in range(nseg):
+        seg = dy[:, s * N:(s + 1) * N].double()
+        _check(dws[s], seg.t() @ x.double(), mode)
+        _check(dbs[s], seg.sum(0), mode)
+
+
+@pytest.mark.parametrize("mode", ["bf16x6"], indirect=True)
+@pytest.mark.parametrize("case", ["tiny_vltasks", "tiny_pretraining_losses", "base_2l2c_b8", "base_6l6c_b2"])
+def test_bf16x6_model_matches_reference_golden(mode, case):
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining, VILBertForVLTasks
+    c = cases.CASES[case]
+    cfg, sd, x = cases.case_inputs(case)
+    conf = BertConfig.from_dict(cfg)
+    m = VILBertForVLTasks(conf, num_labels=1) if c["kind"] == "vltasks" else BertForMultiModalPreTraining(conf)
+    m.load_state_dict(sd)
+    m = m.eval().to(DEV)
+    with torch.no_grad():
+        out = m(*helpers.to_device(cases.forward_args(case, x), DEV))
+    gold = helpers.load_golden(case)
+    for i, n in enumerate(cases.output_names(case)):
+        helpers.assert_close(cases.sample(case, n, out[i]), gold[n], "%s/%s [%s]" % (case, n, mode))

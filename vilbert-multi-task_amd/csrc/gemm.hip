@@ -29,41 +29,13 @@
 //
 // Workgroup -> tile map is XCD aware: block b runs on XCD b % 8, so XCD x gets a contiguous run
 // of logical tiles (N fastest) and the blocks sharing an A panel share one L2.
-#include "common.h"
+#include <string.h>
+
+#include "gemm_core.h"
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int KC_LD = BK + 4;
-constexpr int OPER_SZ = 128 * KC_LD;         // 2560 floats >= 16 * 132 (row-contiguous big tile)
-constexpr int STAGE_SZ = 2 * OPER_SZ;        // A + B
-constexpr int GEMM_LDS_BYTES = 2 * STAGE_SZ * 4;  // 40,960 B
-
-enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC };
-
-struct GemmP {
-    int M, N, K;
-    const float* A; long lda;
-    const float* B[VB_MAX_SEGMENTS]; long ldb; int bseg;   // B row segments (stacked weights)
-    const float* bias[VB_MAX_SEGMENTS];
-    float* C[VB_MAX_SEGMENTS]; long ldc; int cseg;          // C row segments (wgrad of stacked weights)
-    float* colsum[VB_MAX_SEGMENTS];  // row-contiguous A only: colsum[i] += sum_k A[i][k] (bias gradient)
-    const float* R; long ldr;
-    float* P; long ldp;
-    int act;
-    int accumulate;       // C += result
-    int tiles_n;          // big-tile grid columns
-    int n_big, n_small;   // blocks [0, n_big): big tiles; [n_big, n_big + n_small): small tiles
-    int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
-    int epi;              // EPI_* fast path of interior tiles
-    int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
-};
-
-// XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).
-__device__ __forceinline__ int xcd_swizzle(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
+using namespace vbgemm;
 
 // Staging of one R x 16 operand tile into registers (R / 64 float4 per thread).
 // k-contiguous operand (global [rows][ld]): thread t owns rows (t >> 2) + 64 it and the four k values
@@ -118,33 +90,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&
         const int f = tid + 256 * it;
         const int off = KC ? (f >> 2) * KC_LD + (f & 3) * 4 : (f / (R / 4)) * (R + 4) + (f % (R / 4)) * 4;
         *reinterpret_cast<f32x4*>(s + off) = reg[it];
-    }
-}
-
-// Branch-free epilogue of a full interior tile. MODE: STORE c = v; GELU c = gelu(v); RES c = v + R;
-// PRE_GELU P = v, c = gelu(v); ACCUM c += v; ATOMIC atomicAdd(c, v)   with v = acc + bias.
-template <int MODE, int TM, int TN>
-__device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict__ cptr, const f32x16 (&acc)[TM][TN],
-                                              const float (&bv)[TN], int row0, int col0) {
-    const float* __restrict__ rbase = MODE == EPI_RES ? p.R + (long)row0 * p.ldr + col0 : nullptr;
-    float* __restrict__ pbase = MODE == EPI_PRE_GELU ? p.P + (long)row0 * p.ldp + col0 : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float v = acc[i][j][r] + bv[j];
-                float* c = cptr + (long)dr * p.ldc + j * 32;
-                if (MODE == EPI_PRE_GELU) pbase[(long)dr * p.ldp + j * 32] = v;
-                if (MODE == EPI_GELU || MODE == EPI_PRE_GELU) v = gelu_erf(v);
-                if (MODE == EPI_RES) v += rbase[(long)dr * p.ldr + j * 32];
-                if (MODE == EPI_ATOMIC) unsafeAtomicAdd(c, v);
-                else if (MODE == EPI_ACCUM) *c += v;
-                else *c = v;
-            }
-        }
     }
 }
 
@@ -272,64 +217,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, float* __restrict__ sm
         __syncthreads();
     }
 
-    // C row segment of this tile (tiles never straddle segments: cseg is a multiple of the tile rows)
-    const int cs = m0 / p.cseg;
-    const int mloc = m0 - cs * p.cseg;  // row of the tile inside its segment
-    if (want_colsum && mloc + tid < p.cseg && m0 + tid < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + tid, csum);
-
-    // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    // Interior tiles with one of the common epilogues take a branch-free specialised path (the generic
-    // predicated loop costs ~2k VALU instructions per wave, during which the matrix pipe starves when
-    // the co-resident blocks reach their epilogues together).
-    const bool lead = blockIdx.y == 0;  // bias / residual are added by one split only
-    float bv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * 32 * TN + j * 32 + l31;
-        bv[j] = 0.f;
-        if (col < p.N && lead) {
-            const int sg = B_KC ? col / p.bseg : 0;  // bias follows the N segmentation of a k-contiguous B
-            const float* bp = p.bias[sg];
-            if (bp != nullptr) bv[j] = bp[col - sg * p.bseg * (B_KC ? 1 : 0)];
-        }
-    }
-    const int row0 = m0 + wm * 32 * TM + 4 * hi, col0 = n0 + wn * 32 * TN + l31;
-    float* cptr = p.C[cs] + (long)(row0 - cs * p.cseg) * p.ldc + col0;
-    if (m0 + RA <= p.M && n0 + RB <= p.N && p.epi != EPI_GENERIC) {
-        switch (p.epi) {
-            case EPI_STORE: epilogue_full<EPI_STORE, TM, TN>(p, cptr, acc, bv, row0, col0); break;
-            case EPI_GELU: epilogue_full<EPI_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
-            case EPI_RES: epilogue_full<EPI_RES, TM, TN>(p, cptr, acc, bv, row0, col0); break;
-            case EPI_PRE_GELU: epilogue_full<EPI_PRE_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
-            case EPI_ACCUM: epilogue_full<EPI_ACCUM, TM, TN>(p, cptr, acc, bv, row0, col0); break;
-            default: epilogue_full<EPI_ATOMIC, TM, TN>(p, cptr, acc, bv, row0, col0); break;
-        }
-        return;
-    }
-    const bool split = gridDim.y > 1;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + j * 32;
-        if (col >= p.N) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-                const int row = row0 + dr;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv[j];
-                if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
-                if (p.act == VB_ACT_GELU) v = gelu_erf(v);
-                else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
-                if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
-                float* c = cptr + (long)dr * p.ldc + j * 32;
-                if (split) unsafeAtomicAdd(c, v);
-                else if (p.accumulate) *c += v;
-                else *c = v;
-            }
-        }
-    }
+    tile_epilogue<TM, TN, A_KC, B_KC>(p, acc, m0, n0, want_colsum, csum);
 }
 
 template <bool A_KC, bool B_KC, bool VEC>
@@ -350,17 +238,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
 }
 
-// Tile plan: full rounds of 256 big tiles, leftover as small tiles when that shortens the tail.
-void plan_tiles(GemmP& p, int splits) {
-    const int tiles_m = (p.M + 127) / 128;
-    p.tiles_n = (p.N + 127) / 128;
-    const int total = tiles_m * p.tiles_n;
-    static const int hybrid = [] { const char* e = getenv("VB_GEMM_HYBRID"); return e ? atoi(e) : 1; }();
-    const int left = total % 256;
-    // 4 * left small tiles cost ceil(4 left / 256) quarter-rounds vs one full big round (= 4)
-    const bool recut = hybrid && splits == 1 && left > 0 && (4 * left + 255) / 256 < 4 && (p.cseg % 64) == 0;
-    p.n_big = recut ? total - left : total;
-    p.n_small = recut ? 4 * left : 0;
+// GEMM arithmetic mode: 0 = exact fp32 MFMA, 3 = bf16x6, 2 = bf16x3 (number of bf16 operand planes).
+int g_gemm_mode = -1;
+
+int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("VB_GEMM_MODE");
+        g_gemm_mode = 0;
+        if (e != nullptr && !strcmp(e, "bf16x6")) g_gemm_mode = 3;
+        if (e != nullptr && !strcmp(e, "bf16x3")) g_gemm_mode = 2;
+    }
+    return g_gemm_mode;
 }
 
 template <bool A_KC, bool B_KC>
@@ -368,6 +256,10 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
     static const int flags = [] { const char* e = getenv("VB_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
     p.flags = flags;
     plan_tiles(p, splits);
+    // VB_GEMM_MODE: "f32" (default) = exact fp32 MFMA; "bf16x6" / "bf16x3" = fp32 emulated on the bf16
+    // matrix cores with 3 / 2 operand planes (gemm_split.hip)
+    const int planes = gemm_mode();
+    if (planes != 0) return launch_gemm_split(st, p, A_KC ? (B_KC ? 0 : 1) : 2, vec, splits, planes);
     dim3 grid(p.n_big + p.n_small, splits), block(256);
     if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, GEMM_LDS_BYTES, st, p);
     else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, GEMM_LDS_BYTES, st, p);
@@ -376,6 +268,12 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
 }
 
 }  // namespace
+
+extern "C" int vb_set_gemm_mode(int planes) {
+    const int prev = gemm_mode();
+    if (planes == 0 || planes == 2 || planes == 3) g_gemm_mode = planes;
+    return prev;
+}
 
 extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     if (a == nullptr || a->A == nullptr || a->C == nullptr) return VB_E_BADARG;

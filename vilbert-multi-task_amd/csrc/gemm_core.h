@@ -1,0 +1,154 @@
+// Shared pieces of the GEMM kernels (gemm.hip: exact-fp32 MFMA; gemm_split.hip: fp32 emulated with
+// bf16 operand splits): launch parameters, tile planning, XCD-aware block map and the fused epilogues.
+#pragma once
+#include "common.h"
+
+namespace vbgemm {
+
+constexpr int BK = 16;
+constexpr int KC_LD = BK + 4;
+constexpr int OPER_SZ = 128 * KC_LD;         // 2560 floats >= 16 * 132 (row-contiguous big tile)
+constexpr int STAGE_SZ = 2 * OPER_SZ;        // A + B
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_SZ * 4;  // 40,960 B
+
+enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC };
+
+struct GemmP {
+    int M, N, K;
+    const float* A; long lda;
+    const float* B[VB_MAX_SEGMENTS]; long ldb; int bseg;   // B row segments (stacked weights)
+    const float* bias[VB_MAX_SEGMENTS];
+    float* C[VB_MAX_SEGMENTS]; long ldc; int cseg;          // C row segments (wgrad of stacked weights)
+    float* colsum[VB_MAX_SEGMENTS];  // row-contiguous A only: colsum[i] += sum_k A[i][k] (bias gradient)
+    const float* R; long ldr;
+    float* P; long ldp;
+    int act;
+    int accumulate;       // C += result
+    int tiles_n;          // big-tile grid columns
+    int n_big, n_small;   // blocks [0, n_big): big tiles; [n_big, n_big + n_small): small tiles
+    int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
+    int epi;              // EPI_* fast path of interior tiles
+    int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
+};
+
+// XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).
+__device__ __forceinline__ int xcd_swizzle(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// Branch-free epilogue of a full interior tile. MODE: STORE c = v; GELU c = gelu(v); RES c = v + R;
+// PRE_GELU P = v, c = gelu(v); ACCUM c += v; ATOMIC atomicAdd(c, v)   with v = acc + bias.
+template <int MODE, int TM, int TN>
+__device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict__ cptr, const f32x16 (&acc)[TM][TN],
+                                              const float (&bv)[TN], int row0, int col0) {
+    const float* __restrict__ rbase = MODE == EPI_RES ? p.R + (long)row0 * p.ldr + col0 : nullptr;
+    float* __restrict__ pbase = MODE == EPI_PRE_GELU ? p.P + (long)row0 * p.ldp + col0 : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[i][j][r] + bv[j];
+                float* c = cptr + (long)dr * p.ldc + j * 32;
+                if (MODE == EPI_PRE_GELU) pbase[(long)dr * p.ldp + j * 32] = v;
+                if (MODE == EPI_GELU || MODE == EPI_PRE_GELU) v = gelu_erf(v);
+                if (MODE == EPI_RES) v += rbase[(long)dr * p.ldr + j * 32];
+                if (MODE == EPI_ATOMIC) unsafeAtomicAdd(c, v);
+                else if (MODE == EPI_ACCUM) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+// Epilogue of one (64 TM) x (64 TN) tile: fused bias gradient (column sums), bias, activation, residual,
+// pre-activation store, plain / accumulating / atomic stores.
+template <int TM, int TN, bool A_KC, bool B_KC>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], const int m0, const int n0,
+                                              const bool want_colsum, const float csum) {
+    constexpr int RA = 64 * TM, RB = 64 * TN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    // C row segment of this tile (tiles never straddle segments: cseg is a multiple of the tile rows)
+    const int cs = m0 / p.cseg;
+    const int mloc = m0 - cs * p.cseg;  // row of the tile inside its segment
+    if (want_colsum && mloc + tid < p.cseg && m0 + tid < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + tid, csum);
+
+    // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // Interior tiles with one of the common epilogues take a branch-free specialised path (the generic
+    // predicated loop costs ~2k VALU instructions per wave, during which the matrix pipe starves when
+    // the co-resident blocks reach their epilogues together).
+    const bool lead = blockIdx.y == 0;  // bias / residual are added by one split only
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + j * 32 + l31;
+        bv[j] = 0.f;
+        if (col < p.N && lead) {
+            const int sg = B_KC ? col / p.bseg : 0;  // bias follows the N segmentation of a k-contiguous B
+            const float* bp = p.bias[sg];
+            if (bp != nullptr) bv[j] = bp[col - sg * p.bseg * (B_KC ? 1 : 0)];
+        }
+    }
+    const int row0 = m0 + wm * 32 * TM + 4 * hi, col0 = n0 + wn * 32 * TN + l31;
+    float* cptr = p.C[cs] + (long)(row0 - cs * p.cseg) * p.ldc + col0;
+    if (m0 + RA <= p.M && n0 + RB <= p.N && p.epi != EPI_GENERIC) {
+        switch (p.epi) {
+            case EPI_STORE: epilogue_full<EPI_STORE, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_GELU: epilogue_full<EPI_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_RES: epilogue_full<EPI_RES, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_PRE_GELU: epilogue_full<EPI_PRE_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_ACCUM: epilogue_full<EPI_ACCUM, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            default: epilogue_full<EPI_ATOMIC, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+        }
+        return;
+    }
+    const bool split = gridDim.y > 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const int row = row0 + dr;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
+                if (p.act == VB_ACT_GELU) v = gelu_erf(v);
+                else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
+                float* c = cptr + (long)dr * p.ldc + j * 32;
+                if (split) unsafeAtomicAdd(c, v);
+                else if (p.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+    }
+}
+
+// Tile plan: full rounds of 256 big tiles, leftover as small tiles when that shortens the tail.
+inline void plan_tiles(GemmP& p, int splits) {
+    const int tiles_m = (p.M + 127) / 128;
+    p.tiles_n = (p.N + 127) / 128;
+    const int total = tiles_m * p.tiles_n;
+    static const int hybrid = [] { const char* e = getenv("VB_GEMM_HYBRID"); return e ? atoi(e) : 1; }();
+    const int left = total % 256;
+    // 4 * left small tiles cost ceil(4 left / 256) quarter-rounds vs one full big round (= 4)
+    const bool recut = hybrid && splits == 1 && left > 0 && (4 * left + 255) / 256 < 4 && (p.cseg % 64) == 0;
+    p.n_big = recut ? total - left : total;
+    p.n_small = recut ? 4 * left : 0;
+}
+
+// gemm_split.hip: same contract as the fp32 kernel, operands split into bf16 planes (see there).
+// layout: 0 = NT (A, B k-contiguous), 1 = NN (B row-contiguous), 2 = TN (both row-contiguous).
+int launch_gemm_split(hipStream_t st, const GemmP& p, int layout, bool vec, int splits, int planes);
+
+}  // namespace vbgemm

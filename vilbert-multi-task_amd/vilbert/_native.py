@@ -95,6 +95,7 @@ _I32, _I64, _F32, _P, _U64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, cty
 SIGNATURES = {
     "vb_abi_version": (ctypes.c_int, []),
     "vb_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "vb_set_gemm_mode": (ctypes.c_int, [ctypes.c_int]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
     "vb_linear_bwd_input": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdInputArgs)]),
     "vb_linear_bwd_weight": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdWeightArgs)]),
@@ -131,6 +132,15 @@ def lib():
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib
+
+
+GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2}
+
+
+def set_gemm_mode(mode):
+    """Select the GEMM arithmetic ("f32" exact-fp32 MFMA | "bf16x6" | "bf16x3"); returns the previous name."""
+    prev = lib().vb_set_gemm_mode(GEMM_MODES[mode])
+    return {v: k for k, v in GEMM_MODES.items()}[prev]
 
 
 def check(code, what):
