@@ -68,7 +68,10 @@ int vb_set_gemm_mode(int planes);
  * bias[s] (seg_n floats) may be NULL. residual (ldr) may be NULL; when given it is added AFTER
  * the activation (the `dense(x) + input_tensor` of BertSelfOutput/BertOutput).
  * preact (ldp) may be NULL; when given the pre-activation (A.W^T + bias) is also stored
- * (saved for backward). N = nseg*seg_n.
+ * (saved for backward). N = nseg*seg_n. dropout_p > 0 applies nn.Dropout to the activated value BEFORE
+ * the residual is added (the `dropout(dense(x)) + input_tensor` of :471-473, 514-516, ...): keep mask =
+ * f(seed, row * N + col), the same function vb_dropout uses, so vb_dropout(dY, seed) is its backward
+ * (C must be contiguous, ldc == N, in that case).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t M, K;
@@ -80,6 +83,8 @@ typedef struct {
     const float* residual;     int64_t ldr;
     float* preact;             int64_t ldp;
     int32_t act;
+    float dropout_p;
+    uint64_t seed;
 } vb_linear_args;
 
 int vb_linear_fwd(void* stream, const vb_linear_args* a);

@@ -83,8 +83,8 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.vb_layernorm_fwd(None, 0, 0, None, None, None, None, 0.0, None, None, None) == -1
     assert lib.vb_attention_bwd(None, None, None) == -1
     assert lib.vb_linear_bwd_input(None, None) == -1 and lib.vb_linear_bwd_weight(None, None) == -1
-    assert lib.vb_layernorm_bwd_workspace(64, 768) == 4 * 2 * 768
-    assert lib.vb_layernorm_bwd_workspace(65, 768) == 8 * 2 * 768
+    assert lib.vb_layernorm_bwd_workspace(16, 768) == 4 * 2 * 768
+    assert lib.vb_layernorm_bwd_workspace(17, 768) == 8 * 2 * 768
 
 
 def test_product_path_has_no_cpu_fallback(native):

@@ -265,3 +265,52 @@ def test_training_mode_with_dropout_runs_and_is_seeded():
     with torch.no_grad():
         a, b = model(*args), model(*args)
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_dropout_fused_into_gemm_epilogue_uses_the_same_mask(ops):
+    # dropout(dense(x)) + residual as ONE launch == GEMM followed by the standalone dropout(+residual) kernel
+    M, N, K = 300, 256, 96   # interior tiles (fast epilogue) and ragged edge tiles (generic epilogue)
+    x, w, b, r = _rand(M, K, seed=1).cuda(), _rand(N, K, seed=2, scale=0.1).cuda(), _rand(N, seed=3).cuda(), \
+        _rand(M, N, seed=4).cuda()
+    fused, _ = ops.linear_fwd(x, [w], [b], residual=r, drop_p=0.25, seed=777)
+    plain, _ = ops.linear_fwd(x, [w], [b])
+    two_step = ops.dropout(plain, 0.25, 777, r)
+    assert torch.allclose(fused, two_step, rtol=1e-6, atol=1e-6)
+    kept = ((fused - r).abs() > 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.02
+
+
+def test_hip_graph_capture_and_replay_of_the_forward():
+    """Every launcher enqueues on torch's current stream and never allocates or synchronises behind torch's
+    back, so a whole forward can be captured into a HIP graph (launch-bound small-batch inference)."""
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg = synth.tiny_config()
+    sd = synth.make_state_dict(cfg, "vltasks")
+    model = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    model.load_state_dict(sd)
+    model = model.eval().to(DEV)
+    x = synth.make_inputs(cfg, 4, 9, 7)
+    names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+             "co_attention_mask"]
+    static = [x[n].to(DEV) for n in names]
+    with torch.no_grad():
+        eager = [o.clone() for o in model(*static)[:9]]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(*static)                      # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = model(*static)[:9]
+        # new inputs through the static buffers, replayed without any Python-side launch
+        y = synth.make_inputs(cfg, 4, 9, 7, seed=99)
+        for buf, n in zip(static, names):
+            buf.copy_(y[n].to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = [o.clone() for o in captured]
+        fresh = model(*static)[:9]
+    for a, b2 in zip(replayed, fresh):
+        assert torch.equal(a, b2)
+    assert not all(torch.equal(a, e) for a, e in zip(replayed, eager))   # the inputs did change

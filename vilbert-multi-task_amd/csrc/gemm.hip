@@ -295,7 +295,12 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     p.R = a->residual; p.ldr = a->ldr;
     p.P = a->preact; p.ldp = a->ldp;
     p.act = a->act; p.accumulate = 0;
-    if (a->act == VB_ACT_NONE && a->preact == nullptr) p.epi = a->residual != nullptr ? EPI_RES : EPI_STORE;
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
+    if (a->dropout_p > 0.f && a->ldc != p.N) return VB_E_ALIGN;
+    p.drop_p = a->dropout_p; p.drop_scale = 1.0f / (1.0f - a->dropout_p); p.seed = a->seed;
+    if (a->dropout_p > 0.f)
+        p.epi = (a->act == VB_ACT_NONE && a->preact == nullptr && a->residual != nullptr) ? EPI_RES_DROP : EPI_GENERIC;
+    else if (a->act == VB_ACT_NONE && a->preact == nullptr) p.epi = a->residual != nullptr ? EPI_RES : EPI_STORE;
     else if (a->act == VB_ACT_GELU && a->residual == nullptr) p.epi = a->preact != nullptr ? EPI_PRE_GELU : EPI_GELU;
     else p.epi = EPI_GENERIC;
     p.ktiles_per_split = (p.K + BK - 1) / BK;

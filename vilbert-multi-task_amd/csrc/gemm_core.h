@@ -2,6 +2,7 @@
 // bf16 operand splits): launch parameters, tile planning, XCD-aware block map and the fused epilogues.
 #pragma once
 #include "common.h"
+#include "rng.h"
 
 namespace vbgemm {
 
@@ -11,7 +12,7 @@ constexpr int OPER_SZ = 128 * KC_LD;         // 2560 floats >= 16 * 132 (row-con
 constexpr int STAGE_SZ = 2 * OPER_SZ;        // A + B
 constexpr int GEMM_LDS_BYTES = 2 * STAGE_SZ * 4;  // 40,960 B
 
-enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC };
+enum { EPI_GENERIC = 0, EPI_STORE, EPI_GELU, EPI_RES, EPI_PRE_GELU, EPI_ACCUM, EPI_ATOMIC, EPI_RES_DROP };
 
 struct GemmP {
     int M, N, K;
@@ -29,6 +30,8 @@ struct GemmP {
     int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
     int epi;              // EPI_* fast path of interior tiles
     int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
+    float drop_p, drop_scale;  // dropout on the activated value, before the residual (0 = off)
+    uint64_t seed;
 };
 
 // XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).
@@ -38,11 +41,13 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nb) {
 }
 
 // Branch-free epilogue of a full interior tile. MODE: STORE c = v; GELU c = gelu(v); RES c = v + R;
-// PRE_GELU P = v, c = gelu(v); ACCUM c += v; ATOMIC atomicAdd(c, v)   with v = acc + bias.
+// PRE_GELU P = v, c = gelu(v); ACCUM c += v; ATOMIC atomicAdd(c, v); RES_DROP c = dropout(v) + R
+// with v = acc + bias.
 template <int MODE, int TM, int TN>
 __device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict__ cptr, const f32x16 (&acc)[TM][TN],
                                               const float (&bv)[TN], int row0, int col0) {
-    const float* __restrict__ rbase = MODE == EPI_RES ? p.R + (long)row0 * p.ldr + col0 : nullptr;
+    const float* __restrict__ rbase =
+        (MODE == EPI_RES || MODE == EPI_RES_DROP) ? p.R + (long)row0 * p.ldr + col0 : nullptr;
     float* __restrict__ pbase = MODE == EPI_PRE_GELU ? p.P + (long)row0 * p.ldp + col0 : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -55,7 +60,11 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict_
                 float* c = cptr + (long)dr * p.ldc + j * 32;
                 if (MODE == EPI_PRE_GELU) pbase[(long)dr * p.ldp + j * 32] = v;
                 if (MODE == EPI_GELU || MODE == EPI_PRE_GELU) v = gelu_erf(v);
-                if (MODE == EPI_RES) v += rbase[(long)dr * p.ldr + j * 32];
+                if (MODE == EPI_RES_DROP) {
+                    const uint64_t idx = (uint64_t)((long)(row0 + dr) * p.N + col0 + j * 32);
+                    v = vb_keep(p.seed, idx, p.drop_p) ? v * p.drop_scale : 0.f;
+                }
+                if (MODE == EPI_RES || MODE == EPI_RES_DROP) v += rbase[(long)dr * p.ldr + j * 32];
                 if (MODE == EPI_ATOMIC) unsafeAtomicAdd(c, v);
                 else if (MODE == EPI_ACCUM) *c += v;
                 else *c = v;
@@ -104,6 +113,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
             case EPI_RES: epilogue_full<EPI_RES, TM, TN>(p, cptr, acc, bv, row0, col0); break;
             case EPI_PRE_GELU: epilogue_full<EPI_PRE_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
             case EPI_ACCUM: epilogue_full<EPI_ACCUM, TM, TN>(p, cptr, acc, bv, row0, col0); break;
+            case EPI_RES_DROP: epilogue_full<EPI_RES_DROP, TM, TN>(p, cptr, acc, bv, row0, col0); break;
             default: epilogue_full<EPI_ATOMIC, TM, TN>(p, cptr, acc, bv, row0, col0); break;
         }
         return;
@@ -124,6 +134,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
                 if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
                 if (p.act == VB_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
+                if (p.drop_p > 0.f) v = vb_keep(p.seed, (uint64_t)((long)row * p.N + col), p.drop_p) ? v * p.drop_scale : 0.f;
                 if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
                 float* c = cptr + (long)dr * p.ldc + j * 32;
                 if (split) unsafeAtomicAdd(c, v);

@@ -278,12 +278,13 @@ extern "C" int vb_additive_mask(void* stream, int64_t n, const void* mask, int32
 //   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
 //   dgamma = sum_rows dy * xhat,  dbeta = sum_rows dy
 // Stage 1: one wave walks LNB_ROWS_PER_WAVE rows keeping its column partials of dgamma / dbeta in
+// registers; the four waves of a block combine theirs through LDS (rows of <= 1024 columns) and write ONE
 // registers and writes them to a workspace row; stage 2 sums the workspace rows column-wise. No
 // atomics: the result is deterministic.
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int LNB_ROWS_PER_WAVE = 16;
+constexpr int LNB_ROWS_PER_WAVE = 4;   // few rows per wave: 9216 rows -> 2304 waves keep the chip's 1024 SIMDs busy
 constexpr int LNB_ROWS_PER_BLOCK = 4 * LNB_ROWS_PER_WAVE;
 
 template <int NV>
@@ -333,7 +334,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int n_col
                 *reinterpret_cast<f32x4*>(dx + row * n_cols + col) = (g[i] - m1 - xh[i] * m2) * rs;
         }
     }
-    float* w = ws + part * 2 * n_cols;
+    constexpr bool BLOCK_REDUCE = NV <= 4;
+    __shared__ f32x4 red[BLOCK_REDUCE ? 3 * 2 * NV * 64 : 1];
+    if (BLOCK_REDUCE) {
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                red[((wave - 1) * 2 * NV + i) * 64 + lane] = dg[i];
+                red[((wave - 1) * 2 * NV + NV + i) * 64 + lane] = db[i];
+            }
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w2 = 0; w2 < 3; ++w2)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                dg[i] += red[(w2 * 2 * NV + i) * 64 + lane];
+                db[i] += red[(w2 * 2 * NV + NV + i) * 64 + lane];
+            }
+    }
+    float* w = ws + (BLOCK_REDUCE ? (long)blockIdx.x : part) * 2 * n_cols;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * 4;
@@ -462,7 +483,8 @@ extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, cons
                                                       workspace));
     VB_LAUNCH_CHECK();
     const int width = 2 * n_cols;
-    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, blocks * 4, width,
+    const long parts = nv_for(n_cols) <= 4 ? blocks : blocks * 4;  // one partial per block / per wave
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, parts, width,
                        workspace, dgamma, dbeta, n_cols);
     VB_LAUNCH_CHECK();
     return 0;

@@ -31,6 +31,8 @@ class LinearArgs(ctypes.Structure):
         ("residual", _c_f32p), ("ldr", ctypes.c_int64),
         ("preact", _c_f32p), ("ldp", ctypes.c_int64),
         ("act", ctypes.c_int32),
+        ("dropout_p", ctypes.c_float),
+        ("seed", ctypes.c_uint64),
     ]
 
 

@@ -24,14 +24,18 @@ def next_seed():
 
 
 class LinearFn(Function):
-    """y = act(x @ cat(W).T + cat(b)) (+ residual). Inputs: x, residual, act, nseg, W..., b..."""
+    """y = dropout(act(x @ cat(W).T + cat(b)), p) (+ residual). Inputs: x, residual, act, nseg, drop_p, W..., b...
+    The dropout mask is regenerated in backward from the saved seed (vb_dropout on the incoming gradient)."""
 
     @staticmethod
-    def forward(ctx, x, residual, act, nseg, *wb):
+    def forward(ctx, x, residual, act, nseg, drop_p, *wb):
         weights, biases = list(wb[:nseg]), list(wb[nseg:])
-        y, pre = ops.linear_fwd(x, weights, biases, act, residual, want_preact=act is not None)
+        seed = next_seed() if drop_p > 0.0 else 0
+        y, pre = ops.linear_fwd(x, weights, biases, act, residual, want_preact=act is not None, drop_p=drop_p,
+                                seed=seed)
         ctx.save_for_backward(x, pre, *weights)
         ctx.act, ctx.nseg = act, nseg
+        ctx.drop = (drop_p, seed)
         ctx.has_bias = [b is not None for b in biases]
         return y
 
@@ -42,16 +46,18 @@ class LinearFn(Function):
         nseg, seg_n, K = ctx.nseg, weights[0].shape[0], weights[0].shape[1]
         dy = dy.contiguous()
         dres = dy if ctx.needs_input_grad[1] else None
+        if ctx.drop[0] > 0.0:
+            dy = ops.dropout(dy, ctx.drop[0], ctx.drop[1])
         dpre = ops.act_bwd(dy, pre, ctx.act) if ctx.act is not None else dy
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dpre, weights, K).view(x.shape)
-        need_w = any(ctx.needs_input_grad[4:4 + nseg])
-        need_b = [ctx.has_bias[s] and ctx.needs_input_grad[4 + nseg + s] for s in range(nseg)]
+        need_w = any(ctx.needs_input_grad[5:5 + nseg])
+        need_b = [ctx.has_bias[s] and ctx.needs_input_grad[5 + nseg + s] for s in range(nseg)]
         dws, dbs = [None] * nseg, [None] * nseg
         if need_w or any(need_b):
             dws, dbs = ops.linear_bwd_weight(dpre, x, nseg, seg_n, need_b)
-        return (dx, dres, None, None) + tuple(dws) + tuple(dbs)
+        return (dx, dres, None, None, None) + tuple(dws) + tuple(dbs)
 
 
 class LayerNormFn(Function):

@@ -58,7 +58,7 @@ def _row_view(x, K):
     return x.view(-1, K), K, tuple(x.shape[:-1])
 
 
-def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
+def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0):
     """act(x @ cat(weights).T + cat(biases)) (+ residual).
 
     x: [..., K] (the last dim must be contiguous; a uniform row stride is allowed, e.g. the first-token
@@ -97,6 +97,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False):
     if pre is not None:
         a.preact, a.ldp = pre.data_ptr(), n_out
     a.act = N.ACT_CODES[act]
+    a.dropout_p, a.seed = float(drop_p), int(seed)
     _timed(lambda: N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd"),
            2.0 * M * n_out * K)
     return y, pre

@@ -198,12 +198,9 @@ class BertSelfAttention(nn.Module):
 
 
 def _dense_dropout_add_norm(dense, dropout, norm, hidden_states, input_tensor):
-    """LayerNorm(dropout(dense(h)) + input). Eval / p = 0: bias + residual are the GEMM epilogue.
-    Training: the dropout kernel applies the mask and adds the residual in one pass."""
-    p = _drop_p(dropout)
-    if p > 0.0:
-        return norm(F.dropout(F.linear(hidden_states, dense.weight, dense.bias), p, residual=input_tensor))
-    return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor))
+    """LayerNorm(dropout(dense(h)) + input): bias, dropout mask and residual add are all the GEMM epilogue
+    (training and eval), followed by one LayerNorm pass."""
+    return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor, drop_p=_drop_p(dropout)))
 
 
 class _ResidualNormOutput(nn.Module):
