@@ -178,8 +178,9 @@ def main():
             k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
         no_decay = [p for n, p in model.named_parameters() if p.requires_grad and any(
             k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
-        opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}],
-                                lr=1e-4, betas=(0.9, 0.98), eps=1e-6, fused=True)
+        from vilbert.optim import AdamW   # native multi-tensor launch, pytorch-transformers 1.0.0 semantics
+        opt = AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}],
+                    lr=1e-4, betas=(0.9, 0.98))   # train_concap.py:465-470
 
         def step():
             opt.zero_grad(set_to_none=True)

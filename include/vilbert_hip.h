@@ -243,6 +243,30 @@ typedef struct {
 int vb_attention_fwd(void* stream, const vb_attention_args* a);
 int vb_attention_bwd(void* stream, const vb_attention_args* a, const vb_attention_grads* g);
 
+/* ------------------------------------------------------------------------------------------
+ * vb_adamw_step: one launch = AdamW update of every tensor listed in `table` (device array).
+ *
+ * Replaces `optimizer.step()` of pytorch-transformers 1.0.0 AdamW (reference train_concap.py:465-470,583-585
+ * with betas (0.9, 0.98); train_tasks.py:426,550 with correct_bias=False): per tensor
+ *   m = beta1 m + (1-beta1) g;  v = beta2 v + (1-beta2) g^2;  p -= step_size m / (sqrt(v) + eps);
+ *   p -= decay p        (decoupled weight decay on the updated value, decay = lr * weight_decay)
+ * step_size = lr * sqrt(1-beta2^t)/(1-beta1^t) (correct_bias) or lr, computed by the caller.
+ * Work is cut into chunks of chunk_elems (multiple of 4) elements: chunk c updates elements
+ * [chunk_off[c], chunk_off[c] + chunk_elems) of tensor chunk_tensor[c]. All three tables live in device
+ * memory; tensors must be 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel;
+    float step_size, beta1, beta2, eps, decay, reserved;
+} vb_adamw_tensor;
+
+int vb_adamw_step(void* stream, int32_t n_chunks, const vb_adamw_tensor* table, const int32_t* chunk_tensor,
+                  const int64_t* chunk_off, int32_t chunk_elems);
+
 #ifdef __cplusplus
 }
 #endif

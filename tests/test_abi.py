@@ -33,7 +33,7 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = ["vb_set_gemm_mode", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
+EXTRA_DECLS = ["vb_adamw_step", "vb_set_gemm_mode", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd"]
 
 
@@ -63,7 +63,8 @@ def test_struct_layouts_match_the_header(native):
     for struct, mirror in (("vb_linear_args", native.LinearArgs), ("vb_attention_args", native.AttentionArgs),
                            ("vb_attention_grads", native.AttentionGrads),
                            ("vb_linear_bwd_input_args", native.LinearBwdInputArgs),
-                           ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs)):
+                           ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs),
+                           ("vb_adamw_tensor", native.AdamWTensor)):
         body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", text))[struct]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

@@ -1,0 +1,68 @@
+"""Optimizer row: schedules on CPU, the native AdamW launch against the oracle
+restatement of pytorch-transformers 1.0.0 AdamW on the GPU."""
+import pytest
+import torch
+
+from oracle import adamw_oracle as ao
+
+
+def test_schedules_and_import_shim():
+    from pytorch_transformers.optimization import AdamW, WarmupConstantSchedule, WarmupLinearSchedule
+    w = torch.nn.Parameter(torch.zeros(4))
+    opt = AdamW([w], lr=2.0)
+    sched = WarmupLinearSchedule(opt, warmup_steps=4, t_total=10)
+    lrs = []
+    for _ in range(12):
+        lrs.append(opt.param_groups[0]["lr"])
+        sched.step()
+    assert lrs[:5] == pytest.approx([0.0, 0.5, 1.0, 1.5, 2.0])
+    assert lrs[5:11] == pytest.approx([2.0 * ao.warmup_linear(s, 4, 10) for s in range(5, 11)])
+    assert lrs[11] == 0.0
+    opt2 = AdamW([w], lr=1.0)
+    s2 = WarmupConstantSchedule(opt2, warmup_steps=2)
+    seen = []
+    for _ in range(4):
+        seen.append(opt2.param_groups[0]["lr"])
+        s2.step()
+    assert seen == pytest.approx([0.0, 0.5, 1.0, 1.0])
+    with pytest.raises(ValueError):
+        AdamW([w], lr=-1.0)
+
+
+def test_adamw_has_no_cpu_fallback():
+    from vilbert.optim import AdamW
+    w = torch.nn.Parameter(torch.ones(8))
+    w.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        AdamW([w]).step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("correct_bias", [True, False])
+def test_native_adamw_matches_oracle(correct_bias):
+    from vilbert.optim import AdamW
+    g0 = torch.Generator().manual_seed(5)
+    shapes = [(300, 77), (65536 * 2 + 3,), (5,), (1024, 768), (1,)]
+    ref_p = [torch.randn(s, generator=g0) for s in shapes]
+    params = [torch.nn.Parameter(p.clone().cuda()) for p in ref_p]
+    groups = [{"params": params[:2], "weight_decay": 0.01}, {"params": params[2:4], "weight_decay": 0.0, "lr": 3e-3},
+              {"params": params[4:], "weight_decay": 0.1}]
+    opt = AdamW(groups, lr=1e-2, betas=(0.9, 0.98), correct_bias=correct_bias)
+    ref_m = [torch.zeros_like(p) for p in ref_p]
+    ref_v = [torch.zeros_like(p) for p in ref_p]
+    hyper = [(1e-2, 0.01), (1e-2, 0.01), (3e-3, 0.0), (3e-3, 0.0), (1e-2, 0.1)]
+    for step in range(1, 6):
+        grads = [torch.randn(s, generator=g0) * 0.1 for s in shapes]
+        for i, (p, g) in enumerate(zip(params, grads)):
+            p.grad = None if (i == 2 and step == 3) else g.cuda()      # a tensor without a gradient is skipped
+        opt.step()
+        for i, g in enumerate(grads):
+            if i == 2 and step == 3:
+                continue
+            t = step if i != 2 or step < 3 else step - 1                 # per-tensor step count
+            ao.adamw_step(ref_p[i], g, ref_m[i], ref_v[i], t, hyper[i][0], (0.9, 0.98), 1e-6, hyper[i][1], correct_bias)
+    for p, r, s in zip(params, ref_p, shapes):
+        err = (p.detach().cpu() - r).abs().max().item()
+        assert err <= 2e-6 * max(1.0, r.abs().max().item()), (s, err)
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}

@@ -91,6 +91,16 @@ class LinearBwdWeightArgs(ctypes.Structure):
     ]
 
 
+class AdamWTensor(ctypes.Structure):
+    """vb_adamw_tensor (64 bytes)"""
+    _fields_ = [
+        ("param", _c_f32p), ("grad", _c_f32p), ("exp_avg", _c_f32p), ("exp_avg_sq", _c_f32p),
+        ("numel", ctypes.c_int64),
+        ("step_size", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+        ("eps", ctypes.c_float), ("decay", ctypes.c_float), ("reserved", ctypes.c_float),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/vilbert_hip.h one to one (checked by
 # tests/test_abi.py against the header text).
 _I32, _I64, _F32, _P, _U64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64
@@ -113,6 +123,7 @@ SIGNATURES = {
     "vb_additive_mask": (ctypes.c_int, [_P, _I64, _P, _I32, _P]),
     "vb_attention_fwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs)]),
     "vb_attention_bwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs), ctypes.POINTER(AttentionGrads)]),
+    "vb_adamw_step": (ctypes.c_int, [_P, _I32, _P, _P, _P, _I32]),
 }
 
 _lib = None

@@ -1,0 +1,152 @@
+"""AdamW + warm-up schedules with the semantics of pytorch-transformers 1.0.0 (the optimizer the reference
+imports: train_concap.py:27,465-476; train_tasks.py:26-30,426-437), the update itself being ONE native
+multi-tensor launch (csrc/optimizer.hip) instead of ~6 torch kernels per parameter tensor.
+
+Also importable as ``pytorch_transformers.optimization`` (shim package next to this one) so that the
+unchanged reference scripts pick it up.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import _native as N
+
+CHUNK_ELEMS = 64 * 1024
+
+
+class AdamW(Optimizer):
+    """Adam with decoupled weight decay; ``correct_bias=False`` reproduces the original BERT optimizer
+    (train_tasks.py:426). State layout (``step``, ``exp_avg``, ``exp_avg_sq``) matches pytorch-transformers, so
+    the ``.tar`` checkpoints the reference scripts write stay interchangeable."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
+        super(AdamW, self).__init__(params, defaults)
+        self._plan_key, self._plan = None, None
+
+    def _build_plan(self, entries, device):
+        """Static part of the launch tables for this set of tensors: chunk lists on the device and a
+        host-side structured array whose grad / hyper-parameter columns are refreshed every step."""
+        tab = np.zeros(len(entries), dtype=np.dtype([
+            ("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("numel", "<i8"),
+            ("step_size", "<f4"), ("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"), ("decay", "<f4"),
+            ("reserved", "<f4")]))
+        assert tab.dtype.itemsize == ctypes.sizeof(N.AdamWTensor)
+        chunk_t, chunk_o = [], []
+        for i, (p, st, _g) in enumerate(entries):
+            tab["param"][i], tab["exp_avg"][i], tab["exp_avg_sq"][i] = p.data_ptr(), st["exp_avg"].data_ptr(), \
+                st["exp_avg_sq"].data_ptr()
+            tab["numel"][i] = p.numel()
+            for off in range(0, p.numel(), CHUNK_ELEMS):
+                chunk_t.append(i)
+                chunk_o.append(off)
+        # two pinned staging copies of the table (the host may run one step ahead of the device) + events
+        nbytes = tab.nbytes
+        pinned = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        return dict(tab=tab, n_chunks=len(chunk_t), pinned=pinned, events=[None, None], turn=0,
+                    dev_tab=torch.empty(nbytes, dtype=torch.uint8, device=device),
+                    chunk_tensor=torch.tensor(chunk_t, dtype=torch.int32, device=device),
+                    chunk_off=torch.tensor(chunk_o, dtype=torch.int64, device=device))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        entries = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+                if not p.is_cuda:
+                    raise RuntimeError("vilbert.optim.AdamW runs on HIP devices only - no CPU fallback")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("vilbert.optim.AdamW needs contiguous fp32 parameters")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p)
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                state["step"] += 1
+                entries.append((p, state, group))
+        if not entries:
+            return loss
+        device = entries[0][0].device
+        key = tuple((p.data_ptr(), st["exp_avg"].data_ptr()) for p, st, _ in entries)
+        if key != self._plan_key:
+            self._plan_key, self._plan = key, self._build_plan(entries, device)
+        plan = self._plan
+        tab = plan["tab"]
+        keep = []
+        for i, (p, st, g) in enumerate(entries):
+            grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            keep.append(grad)
+            b1, b2 = g["betas"]
+            step_size = g["lr"]
+            if g["correct_bias"]:
+                step_size = step_size * math.sqrt(1.0 - b2 ** st["step"]) / (1.0 - b1 ** st["step"])
+            tab["grad"][i] = grad.data_ptr()
+            tab["step_size"][i], tab["beta1"][i], tab["beta2"][i] = step_size, b1, b2
+            tab["eps"][i], tab["decay"][i] = g["eps"], g["lr"] * g["weight_decay"]
+        # asynchronous upload through pinned memory: no host <-> device synchronisation in step()
+        k = plan["turn"]
+        plan["turn"] = k ^ 1
+        if plan["events"][k] is not None:
+            plan["events"][k].synchronize()
+        plan["pinned"][k].numpy()[:] = tab.view(np.uint8).reshape(-1)
+        dev_tab = plan["dev_tab"]
+        dev_tab.copy_(plan["pinned"][k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        plan["events"][k] = ev
+        N.check(N.lib().vb_adamw_step(N.stream_ptr(), plan["n_chunks"], dev_tab.data_ptr(),
+                                      plan["chunk_tensor"].data_ptr(), plan["chunk_off"].data_ptr(), CHUNK_ELEMS),
+                "vb_adamw_step")
+        return loss
+
+
+class ConstantLRSchedule(LambdaLR):
+    def __init__(self, optimizer, last_epoch=-1):
+        super(ConstantLRSchedule, self).__init__(optimizer, lambda _: 1.0, last_epoch=last_epoch)
+
+
+class WarmupConstantSchedule(LambdaLR):
+    """Linear warm-up 0 -> 1 over ``warmup_steps`` steps, then constant (train_tasks.py:437)."""
+
+    def __init__(self, optimizer, warmup_steps, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        super(WarmupConstantSchedule, self).__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1.0, self.warmup_steps))
+        return 1.0
+
+
+class WarmupLinearSchedule(LambdaLR):
+    """Linear warm-up 0 -> 1 over ``warmup_steps``, then linear decay to 0 at ``t_total``
+    (train_concap.py:472-476, train_tasks.py:433-435)."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, last_epoch=-1):
+        self.warmup_steps, self.t_total = warmup_steps, t_total
+        super(WarmupLinearSchedule, self).__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
