@@ -314,3 +314,25 @@ def test_hip_graph_capture_and_replay_of_the_forward():
     for a, b2 in zip(replayed, fresh):
         assert torch.equal(a, b2)
     assert not all(torch.equal(a, e) for a, e in zip(replayed, eager))   # the inputs did change
+
+
+def test_fixed_layers_run_without_grad_and_train_the_rest():
+    # fixed_t_layer prefix under no_grad (reference vilbert.py:968-995)
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg = synth.tiny_config(fixed_t_layer=1, **NO_DROPOUT)   # text layer 0 frozen; t_biattention_id = [1, 2]
+    sd = synth.make_state_dict(cfg, "vltasks")
+    x = synth.make_inputs(cfg, 3, 6, 5)
+    model = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    args = helpers.to_device((x["input_ids"], x["image_feat"], x["image_loc"], x["token_type_ids"],
+                              x["attention_mask"], x["image_attention_mask"], x["co_attention_mask"]), DEV)
+    out = model(*args)
+    (out[0].sum() + out[7].sum() * 1e-3).backward()
+    params = dict(model.named_parameters())
+    frozen = [n for n in params if n.startswith("bert.encoder.layer.0.")]
+    assert frozen and all(params[n].grad is None for n in frozen)
+    assert model.bert.encoder.layer[1].attention.self.query.weight.grad is not None
+    # the text embeddings feed only the frozen prefix, so they receive no gradient through the encoder
+    assert model.bert.embeddings.position_embeddings.weight.grad is None
+    assert model.bert.v_embeddings.image_embeddings.weight.grad is not None
