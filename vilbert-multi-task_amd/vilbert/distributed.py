@@ -37,6 +37,7 @@ class _Bucket(object):
 
     def reset(self):
         self.ready = set()
+        self.events = {}     # param index -> event recorded on the stream that produced its gradient
         self.work = None
         self.launched = False
 
@@ -96,6 +97,12 @@ class DistributedDataParallel(nn.Module):
                 torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
             b, i = self._where[id(param)]
             b.ready.add(i)
+            if param.grad is not None and param.grad.is_cuda:
+                # the model runs its text / image streams on two HIP streams, so gradients of one bucket
+                # are produced on different streams: remember where, the packer waits for all of them
+                ev = torch.cuda.Event()
+                ev.record()
+                b.events[i] = ev
             if not self.delay_allreduce and self._never_used is not None and not b.launched \
                     and len(b.ready) >= b.expected:
                 self._launch(b)
@@ -103,6 +110,10 @@ class DistributedDataParallel(nn.Module):
 
     def _launch(self, b):
         """Pack the bucket (one multi-tensor copy; unused slices are zero) and start its all-reduce."""
+        if b.events:
+            cur = torch.cuda.current_stream()
+            for ev in b.events.values():
+                cur.wait_event(ev)
         src, dst = [], []
         for i, p in enumerate(b.params):
             if p.grad is not None and p.grad.data_ptr() != b.views[i].data_ptr():

@@ -16,6 +16,7 @@ never used. There is no CPU path: calling a model on CPU tensors raises.
 import copy
 import json
 import logging
+import os
 import sys
 
 import torch
@@ -81,6 +82,44 @@ class BertConfig(object):
 
     def to_json_string(self):
         return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+
+# Two HIP streams: the text and the image stream of the encoder are independent between two connection
+# layers (and so are the two halves of a connection layer around the bi-attention), so their kernels can
+# share the chip - one stream's LayerNorm / attention / tail tiles run beside the other's GEMMs. Autograd
+# replays every backward op on the stream its forward ran on, so the overlap carries over to backward.
+# VB_TWO_STREAMS=0 turns it off.
+_TWO_STREAMS = os.environ.get("VB_TWO_STREAMS", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _concurrent(side_fn, main_fn, side_inputs):
+    """Run side_fn() on the side stream and main_fn() on the current stream, join, return both results.
+    side_inputs: tensors (allocated on the current stream) the side work reads. Falls back to sequential
+    execution (side first) when two-stream mode is off, on CPU tensors, or while a graph is being captured."""
+    t0 = side_inputs[0]
+    if not (_TWO_STREAMS and t0.is_cuda) or torch.cuda.is_current_stream_capturing():
+        return side_fn(), main_fn()
+    main = torch.cuda.current_stream(t0.device)
+    side = _side_stream(t0.device)
+    side.wait_stream(main)
+    for t in side_inputs:
+        t.record_stream(side)       # allocated on `main`, consumed by kernels on `side`
+    with torch.cuda.stream(side):
+        a = side_fn()
+    b = main_fn()
+    main.wait_stream(side)
+    for t in (a if isinstance(a, (tuple, list)) else (a,)):
+        if torch.is_tensor(t):
+            t.record_stream(main)   # allocated on `side`, consumed from here on by kernels on `main`
+    return a, b
 
 
 def _act_name(act):
@@ -377,10 +416,12 @@ class BertBiAttention(nn.Module):
     def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
                 use_co_attention_mask=False):
         H = self.all_head_size
-        qkv1 = F.linear(input_tensor1, [self.query1.weight, self.key1.weight, self.value1.weight],
-                        [self.query1.bias, self.key1.bias, self.value1.bias])
-        qkv2 = F.linear(input_tensor2, [self.query2.weight, self.key2.weight, self.value2.weight],
-                        [self.query2.bias, self.key2.bias, self.value2.bias])
+        qkv1, qkv2 = _concurrent(   # the image-side and text-side projections are independent
+            lambda: F.linear(input_tensor1, [self.query1.weight, self.key1.weight, self.value1.weight],
+                             [self.query1.bias, self.key1.bias, self.value1.bias]),
+            lambda: F.linear(input_tensor2, [self.query2.weight, self.key2.weight, self.value2.weight],
+                             [self.query2.bias, self.key2.bias, self.value2.bias]),
+            [input_tensor1])
         # context_layer1: text queries over image keys / values -> TEXT stream (:768-785, dropout1)
         # context_layer2: image queries over text keys / values -> IMAGE stream (:787-809, dropout2)
         context_layer1, context_layer2, probs1, probs2 = F.bi_attention(
@@ -437,9 +478,17 @@ class BertConnectionLayer(nn.Module):
             use_co_attention_mask)
         # cross-wiring of the reference call site (:890-892): the image stream takes the context
         # computed from image queries (bi_output2), the text stream the one from text queries.
-        attention_output1, attention_output2 = self.biOutput(bi_output2, input_tensor1, bi_output1, input_tensor2)
-        layer_output1 = self.v_output(self.v_intermediate(attention_output1), attention_output1)
-        layer_output2 = self.t_output(self.t_intermediate(attention_output2), attention_output2)
+        bo = self.biOutput
+
+        def image_branch():
+            a1 = _dense_dropout_add_norm(bo.dense1, bo.dropout1, bo.LayerNorm1, bi_output2, input_tensor1)
+            return self.v_output(self.v_intermediate(a1), a1)
+
+        def text_branch():
+            a2 = _dense_dropout_add_norm(bo.dense2, bo.dropout2, bo.LayerNorm2, bi_output1, input_tensor2)
+            return self.t_output(self.t_intermediate(a2), a2)
+
+        layer_output1, layer_output2 = _concurrent(image_branch, text_branch, [bi_output2, input_tensor1])
         return layer_output1, layer_output2, co_attention_probs
 
 
@@ -471,6 +520,7 @@ class BertEncoder(nn.Module):
         batch_size, num_words, t_hidden_size = txt_embedding.size()
         _, num_regions, v_hidden_size = image_embedding.size()
         use_co_attention_mask = False
+        dynamic = len(self.v_layer) > 0 and self.v_layer[0].attention.self.dynamic_attention
 
         def run_text(lo, hi, x, frozen=False):
             for idx in range(lo, hi):
@@ -491,14 +541,26 @@ class BertEncoder(nn.Module):
         for v_end, t_end in zip(self.v_biattention_id, self.t_biattention_id):
             assert self.fixed_t_layer <= t_end
             assert self.fixed_v_layer <= v_end
-            if t_start < self.fixed_t_layer:
-                txt_embedding = run_text(t_start, self.fixed_t_layer, txt_embedding, frozen=True)
-                t_start = self.fixed_t_layer
-            txt_embedding = run_text(t_start, t_end, txt_embedding)
-            if v_start < self.fixed_v_layer:
-                image_embedding = run_image(v_start, self.fixed_v_layer, image_embedding, frozen=True)
-                v_start = self.fixed_v_layer
-            image_embedding = run_image(v_start, v_end, image_embedding)
+            def text_part(x=txt_embedding, lo=t_start, hi=t_end):
+                if lo < self.fixed_t_layer:
+                    x = run_text(lo, self.fixed_t_layer, x, frozen=True)
+                    lo = self.fixed_t_layer
+                return run_text(lo, hi, x)
+
+            def image_part(x=image_embedding, lo=v_start, hi=v_end):
+                if lo < self.fixed_v_layer:
+                    x = run_image(lo, self.fixed_v_layer, x, frozen=True)
+                    lo = self.fixed_v_layer
+                return run_image(lo, hi, x)
+
+            if t_end > t_start and v_end > v_start and not dynamic:
+                # independent stretches of the two streams: image layers on the side stream
+                image_embedding, txt_embedding = _concurrent(image_part, text_part,
+                                                             [image_embedding, image_attention_mask])
+            else:   # (dynamic attention makes the image layers read the UPDATED text stream, :577-586)
+                txt_embedding = text_part()
+                image_embedding = image_part()
+            t_start, v_start = max(t_start, self.fixed_t_layer), max(v_start, self.fixed_v_layer)
 
             if count == 0 and self.in_batch_pairs:
                 # every caption against every image: batch becomes batch_size ** 2 (:1008-1040)
@@ -535,8 +597,13 @@ class BertEncoder(nn.Module):
                 all_encoder_layers_t.append(txt_embedding)
                 all_encoder_layers_v.append(image_embedding)
 
-        image_embedding = run_image(v_start, len(self.v_layer), image_embedding)
-        txt_embedding = run_text(t_start, len(self.layer), txt_embedding)
+        if len(self.v_layer) > v_start and len(self.layer) > t_start and not dynamic:
+            image_embedding, txt_embedding = _concurrent(
+                lambda: run_image(v_start, len(self.v_layer), image_embedding),
+                lambda: run_text(t_start, len(self.layer), txt_embedding), [image_embedding, image_attention_mask])
+        else:
+            image_embedding = run_image(v_start, len(self.v_layer), image_embedding)
+            txt_embedding = run_text(t_start, len(self.layer), txt_embedding)
 
         if not output_all_encoded_layers:
             all_encoder_layers_t.append(txt_embedding)
