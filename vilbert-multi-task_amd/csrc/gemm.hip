@@ -1,6 +1,8 @@
 // fp32 GEMM family on v_mfma_f32_32x32x2_f32 (exact-fp32 matrix cores, 157.3 TFLOP/s peak on
 // gfx950) with fused epilogues. One kernel template covers the three operand layouts the
 // encoder needs:
+// (opt-in: the same tiles with fragments split into bf16 planes in registers and multiplied on
+// v_mfma_f32_32x32x16_bf16 - "bf16x6" / "bf16x3", see gemm_tile):
 //   forward  (NT)  C[M,N] = A[M,K] . W[N,K]^T        A k-contiguous,  B k-contiguous
 //   dgrad    (NN)  dX[M,K'] = dY[M,N'] . W[N',K']    A k-contiguous,  B j-contiguous
 //   wgrad    (TN)  dW[N',K'] = dY[M,N']^T . X[M,K']  A i-contiguous,  B j-contiguous
@@ -93,8 +95,40 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// Exact split of 8 fp32 values (a lane's 8 consecutive k of one row) into NPL bf16x8 MFMA fragments:
+// x = x0 + x1 (+ x2), x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1); each residual is exact.
+template <int NPL>
+__device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, bf16x8 (&out)[NPL]) {
+    float r[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w[q] = cvt_pk_bf16(r[2 * q], r[2 * q + 1]);
+            if (pl + 1 < NPL) {
+                r[2 * q] -= __uint_as_float(w[q] << 16);
+                r[2 * q + 1] -= __uint_as_float(w[q] & 0xFFFF0000u);
+            }
+        }
+        const uint4 packed = make_uint4(w[0], w[1], w[2], w[3]);
+        out[pl] = *reinterpret_cast<const bf16x8*>(&packed);
+    }
+}
+
 // One (64 TM) x (64 TN) output tile at (m0, n0).
-template <int TM, int TN, bool A_KC, bool B_KC, bool VEC>
+// PREC = 0: exact fp32 products on v_mfma_f32_32x32x2_f32. PREC = 3 / 2 ("bf16x6" / "bf16x3"): the SAME
+// fp32 tiles in LDS, but every fragment (8 consecutive k per lane) is split into 3 / 2 bf16 planes in
+// registers as it is read and the 6 / 3 largest partial products run on v_mfma_f32_32x32x16_bf16.
+template <int TM, int TN, bool A_KC, bool B_KC, bool VEC, int PREC>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, float* __restrict__ smem, const int m0, const int n0) {
     constexpr int RA = 64 * TM, RB = 64 * TN;   // operand tile rows
     constexpr int NA = RA / 64, NB = RB / 64;   // float4 per thread per operand tile
@@ -167,39 +201,92 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, float* __restrict__ sm
         if (more) load_ab(kt + 1);
 
         if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
+        if (PREC == 0) {
 #pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {
-            f32x4 af[TM], bf[TN];
+            for (int kc = 0; kc < BK / 8; ++kc) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    if (A_KC) {
+                        af[t] = *reinterpret_cast<const f32x4*>(
+                            sA + (wm * 32 * TM + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            af[t][e] = sA[(kc * 8 + hi * 4 + e) * (RA + 4) + wm * 32 * TM + t * 32 + l31];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    if (B_KC) {
+                        bf[t] = *reinterpret_cast<const f32x4*>(
+                            sB + (wn * 32 * TN + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            bf[t][e] = sB[(kc * 8 + hi * 4 + e) * (RB + 4) + wn * 32 * TN + t * 32 + l31];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                            acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // bf16 MFMA operand convention (32x32x16): lane l supplies row l & 31, k = 8 (l >> 5) .. +7.
+            constexpr int NPL = PREC == 0 ? 1 : PREC;
+            bf16x8 ap[TM][NPL], bp[TN][NPL];
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
+                f32x4 lo, hi4;
                 if (A_KC) {
-                    af[t] = *reinterpret_cast<const f32x4*>(
-                        sA + (wm * 32 * TM + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                    const float* q = sA + (wm * 32 * TM + t * 32 + l31) * KC_LD + hi * 8;
+                    lo = *reinterpret_cast<const f32x4*>(q);
+                    hi4 = *reinterpret_cast<const f32x4*>(q + 4);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        af[t][e] = sA[(kc * 8 + hi * 4 + e) * (RA + 4) + wm * 32 * TM + t * 32 + l31];
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = sA[(hi * 8 + e) * (RA + 4) + wm * 32 * TM + t * 32 + l31];
+                        hi4[e] = sA[(hi * 8 + 4 + e) * (RA + 4) + wm * 32 * TM + t * 32 + l31];
+                    }
                 }
+                split8<NPL>(lo, hi4, ap[t]);
             }
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
+                f32x4 lo, hi4;
                 if (B_KC) {
-                    bf[t] = *reinterpret_cast<const f32x4*>(
-                        sB + (wn * 32 * TN + t * 32 + l31) * KC_LD + kc * 8 + hi * 4);
+                    const float* q = sB + (wn * 32 * TN + t * 32 + l31) * KC_LD + hi * 8;
+                    lo = *reinterpret_cast<const f32x4*>(q);
+                    hi4 = *reinterpret_cast<const f32x4*>(q + 4);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        bf[t][e] = sB[(kc * 8 + hi * 4 + e) * (RB + 4) + wn * 32 * TN + t * 32 + l31];
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = sB[(hi * 8 + e) * (RB + 4) + wn * 32 * TN + t * 32 + l31];
+                        hi4[e] = sB[(hi * 8 + 4 + e) * (RB + 4) + wn * 32 * TN + t * 32 + l31];
+                    }
                 }
+                split8<NPL>(lo, hi4, bp[t]);
             }
+            // partial products, smallest magnitude first, product-major (consecutive MFMAs hit different
+            // accumulators): NPL 3: a2b0 a0b2 a1b1 a1b0 a0b1 a0b0;  NPL 2: a1b0 a0b1 a0b0
+            constexpr int NPROD = NPL == 3 ? 6 : 3;
+            constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int pr = 0; pr < NPROD; ++pr) {
+                const int pa = NPL == 3 ? PA3[pr] : PA2[pr % 3], pb = NPL == 3 ? PB3[pr] : PB2[pr % 3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                        acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][pa % NPL], bp[j][pb % NPL],
+                                                                           acc[i][j], 0, 0, 0);
+            }
         }
         if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
 
@@ -220,13 +307,13 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, float* __restrict__ sm
     tile_epilogue<TM, TN, A_KC, B_KC>(p, acc, m0, n0, want_colsum, csum);
 }
 
-template <bool A_KC, bool B_KC, bool VEC>
+template <bool A_KC, bool B_KC, bool VEC, int PREC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < p.n_big) {
         const int t = xcd_swizzle(b, p.n_big);
-        gemm_tile<2, 2, A_KC, B_KC, VEC>(p, smem, (t / p.tiles_n) * 128, (t % p.tiles_n) * 128);
+        gemm_tile<2, 2, A_KC, B_KC, VEC, PREC>(p, smem, (t / p.tiles_n) * 128, (t % p.tiles_n) * 128);
     } else {
         // leftover big tiles, re-cut into four 64x64 tiles each
         const int s = xcd_swizzle(b - p.n_big, p.n_small);
@@ -234,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         const int m0 = (t / p.tiles_n) * 128 + ((s >> 1) & 1) * 64;
         const int n0 = (t % p.tiles_n) * 128 + (s & 1) * 64;
         if (m0 >= p.M || n0 >= p.N) return;
-        gemm_tile<1, 1, A_KC, B_KC, VEC>(p, smem, m0, n0);
+        gemm_tile<1, 1, A_KC, B_KC, VEC, PREC>(p, smem, m0, n0);
     }
 }
 
@@ -259,10 +346,17 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
     // VB_GEMM_MODE: "f32" (default) = exact fp32 MFMA; "bf16x6" / "bf16x3" = fp32 emulated on the bf16
     // matrix cores with 3 / 2 operand planes (gemm_split.hip)
     const int planes = gemm_mode();
-    if (planes != 0) return launch_gemm_split(st, p, A_KC ? (B_KC ? 0 : 1) : 2, vec, splits, planes);
     dim3 grid(p.n_big + p.n_small, splits), block(256);
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, GEMM_LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, GEMM_LDS_BYTES, st, p);
+    if (planes == 3) {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 3>), grid, block, GEMM_LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 3>), grid, block, GEMM_LDS_BYTES, st, p);
+    } else if (planes == 2) {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 2>), grid, block, GEMM_LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 2>), grid, block, GEMM_LDS_BYTES, st, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true, 0>), grid, block, GEMM_LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false, 0>), grid, block, GEMM_LDS_BYTES, st, p);
+    }
     VB_LAUNCH_CHECK();
     return 0;
 }

@@ -1,5 +1,5 @@
-// Shared pieces of the GEMM kernels (gemm.hip: exact-fp32 MFMA; gemm_split.hip: fp32 emulated with
-// bf16 operand splits): launch parameters, tile planning, XCD-aware block map and the fused epilogues.
+// Shared pieces of the GEMM kernels (gemm.hip): launch parameters, tile planning, XCD-aware block map and
+// the fused epilogues.
 #pragma once
 #include "common.h"
 #include "rng.h"
@@ -157,9 +157,5 @@ inline void plan_tiles(GemmP& p, int splits) {
     p.n_big = recut ? total - left : total;
     p.n_small = recut ? 4 * left : 0;
 }
-
-// gemm_split.hip: same contract as the fp32 kernel, operands split into bf16 planes (see there).
-// layout: 0 = NT (A, B k-contiguous), 1 = NN (B row-contiguous), 2 = TN (both row-contiguous).
-int launch_gemm_split(hipStream_t st, const GemmP& p, int layout, bool vec, int splits, int planes);
 
 }  // namespace vbgemm
