@@ -50,12 +50,40 @@ def model_flops_per_sample(cfg, T, R, heads="vltasks"):
 
 
 def build_model(cfg, kind, device):
-    from oracle import synth
+    """Random-init weights of the named architecture (the classes' own init_weights, reference
+    vilbert.py:1265-1277 semantics) - there are no checkpoints on the bench box."""
     from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining, VILBertForVLTasks
+    torch.manual_seed(1234)
     c = BertConfig.from_dict(cfg)
     model = VILBertForVLTasks(c, num_labels=1) if kind == "vltasks" else BertForMultiModalPreTraining(c)
-    model.load_state_dict(synth.make_state_dict(cfg, kind))
     return model.to(device)
+
+
+def synthetic_batch(cfg, batch, n_tok, n_reg, seed, with_labels):
+    """One loader-shaped batch: full-length token / region rows, box features in
+    [0, 2), normalised box coordinates, and - for the pre-training step - the ConceptCap loader's label
+    conventions (reference vilbert/datasets/concept_cap_dataset.py:244-282,608-670): ~15 % of tokens and
+    regions labelled, -1 elsewhere, region targets are probability rows, region 0 is the global feature."""
+    g = torch.Generator().manual_seed(seed)
+    V, Fv = cfg["vocab_size"], cfg["v_feature_size"]
+    ids = torch.randint(0, V, (batch, n_tok), generator=g)
+    ids[:, 0] = 101
+    loc = torch.rand(batch, n_reg, 5, generator=g)
+    loc[:, 0] = torch.tensor([0.0, 0.0, 1.0, 1.0, 1.0])
+    x = dict(input_ids=ids, image_feat=torch.rand(batch, n_reg, Fv, generator=g) * 2.0, image_loc=loc,
+             token_type_ids=torch.zeros(batch, n_tok, dtype=torch.long),
+             attention_mask=torch.ones(batch, n_tok, dtype=torch.long),
+             image_attention_mask=torch.ones(batch, n_reg, dtype=torch.long),
+             co_attention_mask=torch.zeros(batch, n_reg, n_tok))
+    if with_labels:
+        lm = torch.where(torch.rand(batch, n_tok, generator=g) < 0.15, ids, torch.full_like(ids, -1))
+        lm[:, 1] = ids[:, 1]
+        il = torch.where(torch.rand(batch, n_reg - 1, generator=g) < 0.15, 1, -1)
+        il[:, 0] = 1
+        x.update(masked_lm_labels=lm, image_label=il,
+                 image_target=torch.softmax(torch.randn(batch, n_reg - 1, cfg["v_target_size"], generator=g), -1),
+                 next_sentence_label=torch.randint(0, 2, (batch,), generator=g))
+    return x
 
 
 def cpu_baseline(cfg, mode, budget_s=25.0):
@@ -144,13 +172,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
-    from oracle import synth
     from vilbert import _native, ops
+    from vilbert.vilbert import BertConfig
     _native.set_gemm_mode(args.gemm_mode)
-    cfg = synth.load_config(CONFIG)
+    cfg = BertConfig.from_json_file(os.path.join(ROOT, "vilbert-multi-task_amd", "config", CONFIG)).to_dict()
     B = args.batch
     if args.mode == "fwd":
-        x = synth.make_inputs(cfg, B, N_TOK, N_REG, seed=7 + rank, ragged=False)
+        x = synthetic_batch(cfg, B, N_TOK, N_REG, 7 + rank, False)
         names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
                  "image_attention_mask", "co_attention_mask"]
         inputs = tuple(x[n].to(device) for n in names)
@@ -166,7 +194,7 @@ def main():
         # region targets), loss = masked-LM + masked-region KL + alignment, backward, gradient
         # all-reduce (N > 1), AdamW step.
         n_reg = N_REG + 1
-        x = synth.make_inputs(cfg, B, N_TOK, n_reg, seed=7 + rank, ragged=False, with_labels=True)
+        x = synthetic_batch(cfg, B, N_TOK, n_reg, 7 + rank, True)
         names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
                  "image_attention_mask", "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
         inputs = tuple(x[n].to(device) for n in names)
@@ -230,11 +258,18 @@ def main():
     # Roofline of the dominant kernel (the fp32-MFMA GEMM family, ~99 % of the FLOPs): every
     # vb_linear_fwd launch of extra profiled steps is bracketed with HIP events on the launch stream.
     prof_steps = 1 if args.mode == "train" else 2
+    # The profiled step runs on ONE stream: with the text / image streams overlapped an event pair would
+    # time a GEMM that shares the chip with the other stream's kernels, not the kernel itself.
+    from vilbert import vilbert as _vb
+    two = _vb.set_two_streams(False)
+    step()
+    torch.cuda.synchronize()
     ops.profile_linear(True)
     for _ in range(prof_steps):
         step()
     torch.cuda.synchronize()
     gemm_ms, gemm_flops, gemm_launches = ops.profile_linear(False)
+    _vb.set_two_streams(two)
 
     if rank == 0:
         bert_f, total_f = model_flops_per_sample(cfg, N_TOK, n_reg, "vltasks" if args.mode == "fwd" else "pretraining")
@@ -284,7 +319,7 @@ def main():
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": traffic_note,
                          "what": "all GEMM launches of %d extra step(s) (fwd%s), algorithmic 2MNK FLOPs / "
-                                 "sum of HIP-event durations" % (prof_steps, "" if args.mode == "fwd" else " + dgrad + wgrad"),
+                                 "sum of HIP-event durations (profiled step single-stream)" % (prof_steps, "" if args.mode == "fwd" else " + dgrad + wgrad"),
                          "launches_per_step": gemm_launches // prof_steps,
                          "avg_launch_us": round(1e3 * gemm_ms / max(gemm_launches, 1), 2),
                          "flops_per_launch_avg": round(gemm_flops / max(gemm_launches, 1), 0)},

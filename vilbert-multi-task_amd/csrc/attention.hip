@@ -339,8 +339,305 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short-sequence fast path (n_q, n_k <= 48: the pre-training / benchmark shape of 36-37 tokens and
+// regions). One 4-wave block owns one (sample, head): K and V (forward, pass 1) or Q and dO (pass 2) are
+// staged ONCE into LDS with coalesced 16-byte loads instead of being re-fetched from L2 by every 16-row
+// tile, and the per-MFMA operand reads become ds_read_b128 / ds_read_b32 (rows padded by 4 floats: both
+// access patterns are conflict free). Same arithmetic, same register layout as the generic kernels
+// above, which were bound by global-load latency (12 dependent load -> MFMA rounds per wave).
+// ------------------------------------------------------------------------------------------------
+constexpr int LDS_MAX_ROWS = 48;
+
+template <int D>
+__device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, long ld, int n_rows) {
+    // [n_rows][D] global (row stride ld) -> [LDS_MAX_ROWS][D + 4] LDS, rows >= n_rows zero-filled
+    constexpr int V4 = D / 4;
+    for (int f = threadIdx.x; f < LDS_MAX_ROWS * V4; f += 256) {
+        const int r = f / V4, c4 = f % V4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < n_rows) v = *reinterpret_cast<const f32x4*>(g + (long)r * ld + c4 * 4);
+        *reinterpret_cast<f32x4*>(s + r * (D + 4) + c4 * 4) = v;
+    }
+}
+
+template <int DS>
+__device__ __forceinline__ void load_frag_lds(f32x4 (&f)[DS], const float* s) {
+#pragma unroll
+    for (int q = 0; q < DS; ++q) f[q] = *reinterpret_cast<const f32x4*>(s + 16 * q);
+}
+
+template <int D, bool BWD>
+__global__ __launch_bounds__(256) void attn_q_lds_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_att[];
+    constexpr int LD = D + 4, DS = D / 16, NT = LDS_MAX_ROWS / 16;
+    float* sK = smem_att;
+    float* sV = smem_att + LDS_MAX_ROWS * LD;
+    const long bh = blockIdx.x;
+    const int h = (int)(bh % p.heads), b = (int)(bh / p.heads);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int nkt = p.n_kt;
+    const bool drop = p.drop_p > 0.f;
+
+    stage_rows<D>(sK, p.K + (long)b * p.n_k * p.ldk + h * D, p.ldk, p.n_k);
+    stage_rows<D>(sV, p.V + (long)b * p.n_k * p.ldv + h * D, p.ldv, p.n_k);
+    __syncthreads();
+    const float* mrow = p.mask != nullptr ? p.mask + (long)b * p.n_k : nullptr;
+
+    for (int qt = wave; qt < p.n_qt; qt += 4) {
+        const int q_row = min(qt * 16 + c, p.n_q - 1);
+        f32x4 qf[DS];
+        load_frag<DS>(qf, p.Q + ((long)b * p.n_q + q_row) * p.ldq + h * D + 4 * g);
+        const long prow = (bh * p.n_q + q_row) * p.n_k;
+
+        f32x4 st[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            st[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (kt < nkt) {
+                f32x4 kf[DS];
+                load_frag_lds<DS>(kf, sK + (kt * 16 + c) * LD + 4 * g);
+                f32x4 acc = dot_tile<DS>(kf, qf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    float v = -INFINITY;
+                    if (key < p.n_k) {
+                        v = __fmul_rn(acc[r], p.scale);
+                        if (mrow != nullptr) v = __fadd_rn(v, mrow[key]);
+                    }
+                    acc[r] = v;
+                    mx = fmaxf(mx, v);
+                }
+                st[kt] = acc;
+            }
+        }
+
+        if (!BWD) {
+            mx = group_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                if (kt < nkt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = expf(st[kt][r] - mx);
+                        st[kt][r] = e;
+                        sum += e;
+                    }
+            sum = group_sum(sum);
+            const float inv = 1.0f / sum;
+            if (p.lse != nullptr && g == 0 && qt * 16 + c < p.n_q) p.lse[bh * p.n_q + qt * 16 + c] = mx + logf(sum);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                if (kt < nkt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = st[kt][r] * inv;
+                        if (drop) {
+                            const int key = kt * 16 + 4 * g + r;
+                            pv = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p) ? pv * p.drop_scale : 0.f;
+                        }
+                        st[kt][r] = pv;
+                    }
+            if (p.probs != nullptr && qt * 16 + c < p.n_q) {
+                float* pr = p.probs + prow;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+                    if (kt < nkt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt * 16 + 4 * g + r;
+                            if (key < p.n_k) pr[key] = st[kt][r];
+                        }
+            }
+        } else {
+            const float lse = p.lse[bh * p.n_q + q_row];
+            f32x4 dof[DS];
+            load_frag<DS>(dof, p.dO + ((long)b * p.n_q + q_row) * p.lddo + h * D + 4 * g);
+            f32x4 dp[NT];
+            float dsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kt < nkt) {
+                    f32x4 vf[DS];
+                    load_frag_lds<DS>(vf, sV + (kt * 16 + c) * LD + 4 * g);
+                    f32x4 acc = dot_tile<DS>(vf, dof);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = min(kt * 16 + 4 * g + r, p.n_k - 1);
+                        const float pv = expf(st[kt][r] - lse);
+                        float d = acc[r];
+                        if (drop) d = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p) ? d * p.drop_scale : 0.f;
+                        st[kt][r] = pv;
+                        acc[r] = d;
+                        dsum += pv * d;
+                    }
+                    dp[kt] = acc;
+                }
+            }
+            dsum = group_sum(dsum);
+            if (g == 0 && qt * 16 + c < p.n_q) p.dvec[bh * p.n_q + qt * 16 + c] = dsum;
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                if (kt < nkt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * (dp[kt][r] - dsum) * p.scale;
+        }
+
+        // forward: O = P V;  backward: dQ = dS K   (B operand rows from LDS, zero rows past n_k)
+        const float* rb = (BWD ? sK : sV) + c;
+        f32x4 oacc[DS];
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* rp = rb + (kt * 16 + 4 * g + r) * LD;
+                    float vv[DS];
+#pragma unroll
+                    for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
+#pragma unroll
+                    for (int dt = 0; dt < DS; ++dt)
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        float* obase = BWD ? p.dQ : p.O;
+        const long ldo = BWD ? p.lddq : p.ldo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * g + r;
+            if (q < p.n_q) {
+                float* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) op[16 * dt] = oacc[dt][r];
+            }
+        }
+    }
+}
+
+// Backward pass 2, short sequences: Q and dO of the (sample, head) staged in LDS, one wave per 16 keys.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_att[];
+    constexpr int LD = D + 4, DS = D / 16;
+    float* sQ = smem_att;
+    float* sO = smem_att + LDS_MAX_ROWS * LD;
+    const long bh = blockIdx.x;
+    const int h = (int)(bh % p.heads), b = (int)(bh / p.heads);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const bool drop = p.drop_p > 0.f;
+
+    stage_rows<D>(sQ, p.Q + (long)b * p.n_q * p.ldq + h * D, p.ldq, p.n_q);
+    stage_rows<D>(sO, p.dO + (long)b * p.n_q * p.lddo + h * D, p.lddo, p.n_q);
+    __syncthreads();
+    const float* lse = p.lse + bh * p.n_q;
+    const float* dvec = p.dvec + bh * p.n_q;
+
+    for (int kt = wave; kt < p.n_kt; kt += 4) {
+        const int key = kt * 16 + c;
+        const int k_row = min(key, p.n_k - 1);
+        const bool key_ok = key < p.n_k;
+        f32x4 kf[DS], vf[DS];
+        load_frag<DS>(kf, p.K + ((long)b * p.n_k + k_row) * p.ldk + h * D + 4 * g);
+        load_frag<DS>(vf, p.V + ((long)b * p.n_k + k_row) * p.ldv + h * D + 4 * g);
+        const float madd = p.mask != nullptr ? p.mask[(long)b * p.n_k + k_row] : 0.f;
+        f32x4 dk[DS], dv[DS];
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt) {
+            dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int qt = 0; qt < p.n_qt; ++qt) {
+            f32x4 qf[DS], dof[DS];
+            load_frag_lds<DS>(qf, sQ + (qt * 16 + c) * LD + 4 * g);     // rows past n_q are zero
+            load_frag_lds<DS>(dof, sO + (qt * 16 + c) * LD + 4 * g);
+            const f32x4 s = dot_tile<DS>(qf, kf);
+            const f32x4 dpr = dot_tile<DS>(dof, vf);
+            float pd[4], dsv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + 4 * g + r;
+                float dsr = 0.f, pdr = 0.f;
+                if (q < p.n_q && key_ok) {
+                    const float sv = __fadd_rn(__fmul_rn(s[r], p.scale), madd);
+                    const float pv = expf(sv - lse[q]);
+                    float d = dpr[r];
+                    pdr = pv;
+                    if (drop) {
+                        const bool keep = vb_keep(p.seed, (uint64_t)((bh * p.n_q + q) * p.n_k + key), p.drop_p);
+                        d = keep ? d * p.drop_scale : 0.f;
+                        pdr = keep ? pv * p.drop_scale : 0.f;
+                    }
+                    dsr = pv * (d - dvec[q]) * p.scale;
+                }
+                pd[r] = pdr;
+                dsv[r] = dsr;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* dop = sO + (qt * 16 + 4 * g + r) * LD + c;
+                const float* qp = sQ + (qt * 16 + 4 * g + r) * LD + c;
+                float dov[DS], qv[DS];
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    dov[dt] = dop[16 * dt];
+                    qv[dt] = qp[16 * dt];
+                }
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[r], dov[dt], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[r], qv[dt], dk[dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = kt * 16 + 4 * g + r;
+            if (kk < p.n_k) {
+                float* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
+                float* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    kp[16 * dt] = dk[dt][r];
+                    vp[16 * dt] = dv[dt][r];
+                }
+            }
+        }
+    }
+}
+
+inline bool use_lds_path(const AttnP& p) {
+    static const int on = [] { const char* e = getenv("VB_ATTN_LDS"); return e ? atoi(e) : 1; }();
+    return on && p.n_q <= LDS_MAX_ROWS && p.n_k <= LDS_MAX_ROWS && p.q_bstride == p.n_q && p.kv_bstride == p.n_k;
+}
+
+template <int D, bool BWD>
+int launch_q_lds(hipStream_t st, const AttnP& p) {
+    constexpr int bytes = 2 * LDS_MAX_ROWS * (D + 4) * 4;
+    hipLaunchKernelGGL((attn_q_lds_kernel<D, BWD>), dim3((unsigned)(p.batch * p.heads)), dim3(256), bytes, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int D>
+int launch_kv_lds(hipStream_t st, const AttnP& p) {
+    constexpr int bytes = 2 * LDS_MAX_ROWS * (D + 4) * 4;
+    hipLaunchKernelGGL((attn_bwd_kv_lds_kernel<D>), dim3((unsigned)(p.batch * p.heads)), dim3(256), bytes, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int D, bool BWD>
 int launch_q(hipStream_t st, const AttnP& p) {
+    if (use_lds_path(p)) return launch_q_lds<D, BWD>(st, p);
     dim3 block(256), grid((unsigned)((p.total + 3) / 4));
     if (p.n_kt <= 3) hipLaunchKernelGGL((attn_q_kernel<D, 3, BWD>), grid, block, 0, st, p);
     else if (p.n_kt <= 8) hipLaunchKernelGGL((attn_q_kernel<D, 8, BWD>), grid, block, 0, st, p);
@@ -352,6 +649,7 @@ int launch_q(hipStream_t st, const AttnP& p) {
 
 template <int D>
 int launch_kv(hipStream_t st, const AttnP& p) {
+    if (use_lds_path(p)) return launch_kv_lds<D>(st, p);
     dim3 block(256), grid((unsigned)((p.total + 3) / 4));
     hipLaunchKernelGGL((attn_bwd_kv_kernel<D>), grid, block, 0, st, p);
     VB_LAUNCH_CHECK();

@@ -93,6 +93,14 @@ _TWO_STREAMS = os.environ.get("VB_TWO_STREAMS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
+def set_two_streams(on):
+    """Turn the text || image stream overlap on / off at run time; returns the previous setting. (bench.py
+    serialises the step it brackets with per-launch HIP events, so kernel durations are not shared-chip times.)"""
+    global _TWO_STREAMS
+    prev, _TWO_STREAMS = _TWO_STREAMS, bool(on)
+    return prev
+
+
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _SIDE_STREAMS:
