@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 2
+#define VB_ABI_VERSION 3
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -266,6 +266,35 @@ typedef struct {
 
 int vb_adamw_step(void* stream, int32_t n_chunks, const vb_adamw_tensor* table, const int32_t* chunk_tensor,
                   const int64_t* chunk_off, int32_t chunk_elems);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses of the pre-training heads, one scalar each.
+ *
+ * vb_xent_fwd: nn.CrossEntropyLoss(ignore_index) on logits [rows, n] (leading dimension ld) with int64
+ * labels [rows] - vilbert.py:1453 (`loss_fct`), :1578-1585 (masked-LM and alignment losses):
+ *   row_loss[r] = logsumexp(logits[r]) - logits[r][label[r]]   (0 for ignored rows),  lse[r] saved,
+ *   loss[0] = sum(row_loss) / count[0],  count[0] = number of rows whose label != ignore_index
+ *   (0 / 0 = NaN when every row is ignored, like torch).
+ * vb_xent_bwd: dlogits[r][j] = (exp(logits[r][j] - lse[r]) - [j == label[r]]) * grad_loss[0] / count[0];
+ * ignored rows get zeros. grad_loss and count are DEVICE scalars (no host sync).
+ *
+ * vb_kl_fwd: sum over rows and classes of nn.KLDivLoss(reduction="none")(log_softmax(scores), target)
+ * divided by `divisor` - vilbert.py:1454,1516-1522 (the caller passes only the labelled region rows, so
+ * the reference's `* (image_label == 1)` mask is the row selection and divisor = their count).
+ *   row_loss[r] = sum_j t_j (log t_j - (s_j - lse[r]))  (terms with t_j == 0 are 0),  tsum[r] = sum_j t_j;
+ *   loss[0] = sum(row_loss) / divisor, loss[1] = divisor  (loss points to TWO floats).
+ * vb_kl_bwd: dscores[r][j] = (exp(s_j - lse[r]) tsum[r] - t_j) * grad_loss[0] / divisor.
+ * ------------------------------------------------------------------------------------------ */
+int vb_xent_fwd(void* stream, int64_t rows, int32_t n, const float* logits, int64_t ld, const int64_t* labels,
+                int64_t ignore_index, float* row_loss, float* lse, float* loss, float* count);
+int vb_xent_bwd(void* stream, int64_t rows, int32_t n, const float* logits, int64_t ld, const int64_t* labels,
+                int64_t ignore_index, const float* lse, const float* grad_loss, const float* count,
+                float* dlogits, int64_t ldd);
+int vb_kl_fwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
+              int64_t ldt, float divisor, float* row_loss, float* lse, float* tsum, float* loss);
+int vb_kl_bwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
+              int64_t ldt, const float* lse, const float* tsum, const float* grad_loss, float divisor,
+              float* dscores, int64_t ldd);
 
 #ifdef __cplusplus
 }

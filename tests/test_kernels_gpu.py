@@ -237,3 +237,54 @@ def test_attention_range_error(ops):
     k = torch.zeros(1, 400, 64).cuda()
     with pytest.raises(RuntimeError):
         ops.attention_fwd(q, k, k, None, 1)
+
+
+@pytest.mark.parametrize("rows,n", [(1, 2), (37, 2), (50, 1601), (123, 30522), (5, 7)])
+def test_cross_entropy_forward_backward(rows, n):
+    """vb_xent_fwd / vb_xent_bwd vs nn.CrossEntropyLoss(ignore_index=-1) in fp64 (reference vilbert.py:1453,
+    1578-1585), through the autograd Function the model uses."""
+    from vilbert import functional as F
+    g = torch.Generator().manual_seed(rows * 31 + n)
+    logits = torch.randn(rows, n, generator=g) * 3.0
+    labels = torch.randint(0, n, (rows,), generator=g)
+    if rows > 2:
+        labels[torch.rand(rows, generator=g) < 0.3] = -1
+        labels[0] = n - 1
+    x = logits.cuda().requires_grad_(True)
+    loss = F.cross_entropy(x, labels.cuda(), ignore_index=-1)
+    (loss * 1.7).backward()
+    x64 = logits.double().requires_grad_(True)
+    want = torch.nn.CrossEntropyLoss(ignore_index=-1)(x64, labels)
+    (want * 1.7).backward()
+    assert loss.dim() == 0
+    _close(loss, want.detach(), rtol=2e-6, atol=1e-6)
+    # p - onehot cancels when p -> 1: absolute error is fp32 roundoff of p (6e-8) times the loss scale
+    _close(x.grad, x64.grad, rtol=2e-5, atol=2e-7)
+    with torch.no_grad():
+        _close(F.cross_entropy(x, labels.cuda()), want.detach(), rtol=2e-6, atol=1e-6)
+
+
+def test_cross_entropy_all_ignored_is_nan_like_torch():
+    from vilbert import functional as F
+    x = torch.randn(4, 9).cuda().requires_grad_(True)
+    loss = F.cross_entropy(x, torch.full((4,), -1, dtype=torch.long).cuda())
+    assert torch.isnan(loss)
+
+
+@pytest.mark.parametrize("rows,n", [(1, 1601), (64, 1601), (9, 33)])
+def test_kl_div_of_log_softmax_forward_backward(rows, n):
+    """vb_kl_fwd / vb_kl_bwd vs sum(KLDivLoss(reduction='none')(log_softmax(s), t)) / count in fp64
+    (reference vilbert.py:1454,1516-1522); targets with exact zeros included."""
+    from vilbert import functional as F
+    g = torch.Generator().manual_seed(rows + n)
+    scores = torch.randn(rows, n, generator=g) * 2.0
+    target = torch.softmax(torch.randn(rows, n, generator=g) * 2.0, -1)
+    target[:, ::5] = 0.0
+    s = scores.cuda().requires_grad_(True)
+    loss = F.kl_div_log_softmax(s, target.cuda(), float(rows))
+    (loss * 0.6).backward()
+    s64 = scores.double().requires_grad_(True)
+    want = torch.nn.KLDivLoss(reduction="none")(torch.log_softmax(s64, 1), target.double()).sum() / rows
+    (want * 0.6).backward()
+    _close(loss, want.detach(), rtol=5e-6, atol=1e-6)
+    _close(s.grad, s64.grad, rtol=2e-5, atol=2e-7)

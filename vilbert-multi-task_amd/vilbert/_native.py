@@ -124,6 +124,10 @@ SIGNATURES = {
     "vb_attention_fwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs)]),
     "vb_attention_bwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs), ctypes.POINTER(AttentionGrads)]),
     "vb_adamw_step": (ctypes.c_int, [_P, _I32, _P, _P, _P, _I32]),
+    "vb_xent_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "vb_xent_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
+    "vb_kl_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _F32, _P, _P, _P, _P]),
+    "vb_kl_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _I64]),
 }
 
 _lib = None
@@ -141,7 +145,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 2:
+        if handle.vb_abi_version() != 3:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib

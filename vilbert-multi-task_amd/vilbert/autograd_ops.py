@@ -193,3 +193,35 @@ class ImageEmbedFn(Function):
         hidden = dsum.shape[-1]
         (dw_loc,), (db_loc,) = ops.linear_bwd_weight(dsum, loc.reshape(-1, 5), 1, hidden, [True])
         return dsum, None, dw_loc, db_loc, dgamma, dbeta, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index) (mean over counted rows) - reference vilbert.py:1453,1578-1585."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        loss, lse, count = ops.xent_fwd(logits, labels, ignore_index)
+        ctx.save_for_backward(logits, labels, lse, count)
+        ctx.ignore_index = ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        logits, labels, lse, count = ctx.saved_tensors
+        return ops.xent_bwd(grad_loss, logits, labels, ctx.ignore_index, lse, count), None, None
+
+
+class KLDivFn(torch.autograd.Function):
+    """sum(KLDivLoss(reduction="none")(log_softmax(scores), target)) / divisor - reference :1454,1516-1522."""
+
+    @staticmethod
+    def forward(ctx, scores, target, divisor):
+        loss, lse, tsum = ops.kl_fwd(scores, target, divisor)
+        ctx.save_for_backward(scores, target, lse, tsum)
+        ctx.divisor = divisor
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        scores, target, lse, tsum = ctx.saved_tensors
+        return ops.kl_bwd(grad_loss, scores, target, lse, tsum, ctx.divisor), None, None

@@ -82,3 +82,17 @@ def image_embed_ln(feat_proj, loc, w_loc, b_loc, gamma, beta, eps):
     if _needs_grad(feat_proj, w_loc, b_loc, gamma, beta):
         return A.ImageEmbedFn.apply(feat_proj, loc, w_loc, b_loc, gamma, beta, eps)
     return ops.image_embed_ln_fwd(feat_proj, loc, w_loc, b_loc, gamma, beta, eps)[0]
+
+
+def cross_entropy(logits, labels, ignore_index=-1):
+    """nn.CrossEntropyLoss(ignore_index=...)(logits [rows, n], labels [rows]) -> 0-dim loss."""
+    if _needs_grad(logits):
+        return A.CrossEntropyFn.apply(logits, labels, ignore_index)
+    return ops.xent_fwd(logits, labels, ignore_index)[0]
+
+
+def kl_div_log_softmax(scores, target, divisor):
+    """sum(nn.KLDivLoss(reduction="none")(log_softmax(scores, 1), target)) / divisor -> 0-dim loss."""
+    if _needs_grad(scores):
+        return A.KLDivFn.apply(scores, target, divisor)
+    return ops.kl_fwd(scores, target, divisor)[0]

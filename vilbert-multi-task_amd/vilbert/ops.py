@@ -343,3 +343,62 @@ def attention_bwd(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p=0.0, 
     dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
     g.dvec = dvec.data_ptr()
     N.check(N.lib().vb_attention_bwd(N.stream_ptr(), ctypes.byref(a), ctypes.byref(g)), "vb_attention_bwd")
+
+
+def xent_fwd(logits, labels, ignore_index):
+    """Mean cross-entropy over the rows whose label != ignore_index. logits [rows, n] fp32, labels [rows]
+    int64. Returns (loss [1]-element 0-dim view, lse [rows], count [1])."""
+    if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+        raise RuntimeError("cross_entropy: expected logits [rows, n] and labels [rows]")
+    logits, labels = _contig(logits), _contig(labels)
+    rows, n = logits.shape
+    dev = logits.device
+    row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+    lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)    # {loss, count}
+    N.check(N.lib().vb_xent_fwd(N.stream_ptr(), rows, n, N.dev_f32(logits, "cross_entropy logits"), n,
+                                N.dev_i64(labels, "cross_entropy labels"), ignore_index, row_loss.data_ptr(),
+                                lse.data_ptr(), out.data_ptr(), out.data_ptr() + 4), "vb_xent_fwd")
+    return out[0], lse, out[1:]
+
+
+def xent_bwd(grad_loss, logits, labels, ignore_index, lse, count):
+    logits, labels = _contig(logits), _contig(labels)
+    rows, n = logits.shape
+    grad_loss = _contig(grad_loss).reshape(1)
+    d = torch.empty_like(logits)
+    N.check(N.lib().vb_xent_bwd(N.stream_ptr(), rows, n, N.dev_f32(logits, "cross_entropy logits"), n,
+                                N.dev_i64(labels, "cross_entropy labels"), ignore_index,
+                                N.dev_f32(lse, "cross_entropy lse"), N.dev_f32(grad_loss, "cross_entropy grad"),
+                                N.dev_f32(count, "cross_entropy count"), d.data_ptr(), n), "vb_xent_bwd")
+    return d
+
+
+def kl_fwd(scores, target, divisor):
+    """sum(KLDiv(log_softmax(scores, 1), target)) / divisor; scores / target [rows, n] fp32.
+    Returns (loss 0-dim, lse [rows], tsum [rows])."""
+    if scores.dim() != 2 or scores.shape != target.shape:
+        raise RuntimeError("kl_div: expected scores and target of the same [rows, n] shape")
+    scores, target = _contig(scores), _contig(target)
+    rows, n = scores.shape
+    dev = scores.device
+    row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+    lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    tsum = torch.empty(rows, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    N.check(N.lib().vb_kl_fwd(N.stream_ptr(), rows, n, N.dev_f32(scores, "kl_div scores"), n,
+                              N.dev_f32(target, "kl_div target"), n, float(divisor), row_loss.data_ptr(),
+                              lse.data_ptr(), tsum.data_ptr(), out.data_ptr()), "vb_kl_fwd")
+    return out[0], lse, tsum
+
+
+def kl_bwd(grad_loss, scores, target, lse, tsum, divisor):
+    scores, target = _contig(scores), _contig(target)
+    rows, n = scores.shape
+    grad_loss = _contig(grad_loss).reshape(1)
+    d = torch.empty_like(scores)
+    N.check(N.lib().vb_kl_bwd(N.stream_ptr(), rows, n, N.dev_f32(scores, "kl_div scores"), n,
+                              N.dev_f32(target, "kl_div target"), n, N.dev_f32(lse, "kl_div lse"),
+                              N.dev_f32(tsum, "kl_div tsum"), N.dev_f32(grad_loss, "kl_div grad"), float(divisor),
+                              d.data_ptr(), n), "vb_kl_bwd")
+    return d

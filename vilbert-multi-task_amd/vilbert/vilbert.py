@@ -899,9 +899,10 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
             masked_img_loss = torch.sum(img_loss * labelled.unsqueeze(2).float()) / max(torch.sum(labelled), 0)
         elif self.visual_target == 2:
             masked_img_loss = self._nce_region_loss(input_ids, prediction_scores_v, image_target, labelled)
-        masked_lm_loss = self.loss_fct(prediction_scores_t.view(-1, self.config.vocab_size),
-                                       masked_lm_labels.view(-1))
-        next_sentence_loss = self.loss_fct(seq_relationship_score.view(-1, 2), next_sentence_label.view(-1))
+        masked_lm_loss = F.cross_entropy(prediction_scores_t.view(-1, self.config.vocab_size),
+                                         masked_lm_labels.reshape(-1), ignore_index=-1)
+        next_sentence_loss = F.cross_entropy(seq_relationship_score.view(-1, 2), next_sentence_label.reshape(-1),
+                                             ignore_index=-1)
         return masked_lm_loss.unsqueeze(0), masked_img_loss.unsqueeze(0), next_sentence_loss.unsqueeze(0)
 
     def _losses_at_labelled_positions(self, sequence_output_t, sequence_output_v, pooled_output_t, pooled_output_v,
@@ -927,10 +928,12 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         pooled_output = _dropout(_fuse_pooled(cls.fusion_method, pooled_output_t, pooled_output_v), cls.dropout)
         seq_relationship_score = F.linear(pooled_output, cls.bi_seq_relationship.weight,
                                           cls.bi_seq_relationship.bias)
-        next_sentence_loss = self.loss_fct(seq_relationship_score.view(-1, 2), next_sentence_label.view(-1))
+        # losses: native row kernels (csrc/loss.hip) - log-sum-exp forward, (softmax - onehot) backward
+        next_sentence_loss = F.cross_entropy(seq_relationship_score.view(-1, 2), next_sentence_label.reshape(-1),
+                                             ignore_index=-1)
 
         rows_t = sequence_output_t.reshape(-1, sequence_output_t.size(-1)).index_select(0, idx_t)
-        masked_lm_loss = self.loss_fct(cls.predictions(rows_t), lm_flat.index_select(0, idx_t))
+        masked_lm_loss = F.cross_entropy(cls.predictions(rows_t), lm_flat.index_select(0, idx_t), ignore_index=-1)
 
         rows_v = sequence_output_v.reshape(-1, sequence_output_v.size(-1)).index_select(0, idx_v)
         scores_v = cls.imagePredictions(rows_v)
@@ -939,8 +942,8 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
             masked_img_loss = torch.sum(self.vis_criterion(scores_v, target)) / max(
                 torch.sum(labelled.unsqueeze(2).expand(-1, -1, image_target.size(-1))), 1)
         else:
-            masked_img_loss = torch.sum(self.vis_criterion(TF.log_softmax(scores_v, dim=1), target)) / max(
-                torch.sum(labelled), 0)
+            # divisor: the reference's max(sum(image_label == 1), 0) (:1520-1522) = the number of rows here
+            masked_img_loss = F.kl_div_log_softmax(scores_v, target, float(idx_r.numel()))
         return masked_lm_loss.unsqueeze(0), masked_img_loss.unsqueeze(0), next_sentence_loss.unsqueeze(0)
 
     def _nce_region_loss(self, input_ids, prediction_scores_v, image_target, labelled):
