@@ -77,7 +77,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict_
 // pre-activation store, plain / accumulating / atomic stores.
 template <int TM, int TN, bool A_KC, bool B_KC>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], const int m0, const int n0,
-                                              const bool want_colsum, const float csum) {
+                                              const bool want_colsum, const float csum, const int crow) {
     constexpr int RA = 64 * TM, RB = 64 * TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -86,7 +86,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
     // C row segment of this tile (tiles never straddle segments: cseg is a multiple of the tile rows)
     const int cs = m0 / p.cseg;
     const int mloc = m0 - cs * p.cseg;  // row of the tile inside its segment
-    if (want_colsum && mloc + tid < p.cseg && m0 + tid < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + tid, csum);
+    // crow = the tile row whose (partial) sum over this block's K range the thread holds
+    if (want_colsum && mloc + crow < p.cseg && m0 + crow < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + crow, csum);
 
     // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     // Interior tiles with one of the common epilogues take a branch-free specialised path (the generic
@@ -146,14 +147,18 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
 }
 
 // Tile plan: full rounds of 256 big tiles, leftover as small tiles when that shortens the tail.
-inline void plan_tiles(GemmP& p, int splits) {
+inline void plan_tiles(GemmP& p, int splits, bool planes_mode) {
     const int tiles_m = (p.M + 127) / 128;
     p.tiles_n = (p.N + 127) / 128;
     const int total = tiles_m * p.tiles_n;
     static const int hybrid = [] { const char* e = getenv("VB_GEMM_HYBRID"); return e ? atoi(e) : 1; }();
     const int left = total % 256;
-    // 4 * left small tiles cost ceil(4 left / 256) quarter-rounds vs one full big round (= 4)
-    const bool recut = hybrid && splits == 1 && left > 0 && (4 * left + 255) / 256 < 4 && (p.cseg % 64) == 0;
+    // 4 * left small tiles cost ceil(4 left / 256) quarter-rounds vs one full big round (= 4). A small tile
+    // runs at ~3/4 of a big tile's MFMA efficiency in the fp32 kernel (re-cut when < 4 quarter-rounds) but
+    // at ~1/2 in the bf16-planes kernel, whose per-thread split work does not shrink with the tile
+    // (re-cut only when the tail fits ONE quarter-round).
+    const int limit = planes_mode ? 2 : 4;
+    const bool recut = hybrid && splits == 1 && left > 0 && (4 * left + 255) / 256 < limit && (p.cseg % 64) == 0;
     p.n_big = recut ? total - left : total;
     p.n_small = recut ? 4 * left : 0;
 }
