@@ -145,17 +145,25 @@ def cpu_baseline(cfg, mode, budget_s=25.0):
 
 
 def main():
+    global CONFIG, N_TOK, N_REG
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["fwd", "train"], default="train")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--config", default=CONFIG, help="model config JSON under vilbert-multi-task_amd/config/ "
+                    "(default = the metric's bert_base_6layer_6conect.json; e.g. bert_large_6layer_6conect.json)")
+    ap.add_argument("--tokens", type=int, default=N_TOK, help="tokens per sample (metric: 36)")
+    ap.add_argument("--regions", type=int, default=N_REG, help="regions per sample (metric: 36; task shapes: 101)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "bf16x3"], default="f32",
                     help="GEMM arithmetic: f32 = exact fp32 MFMA (default); bf16x6 = fp32 emulated with 6 bf16 "
                          "MFMA products (fp32-class); bf16x3 = 3 products")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra bf16x6 measurement")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="(train, 1 GPU) also time the step fed from HOST numpy batches through the device input "
+                         "pipeline (pinned double-buffered H2D + vb_concap_finish_batch): the PCIe-inclusive rate")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even at world size 1 "
                     "(exercises the RCCL bucket path on a single GPU)")
     args = ap.parse_args()
@@ -175,6 +183,7 @@ def main():
     from vilbert import _native, ops
     from vilbert.vilbert import BertConfig
     _native.set_gemm_mode(args.gemm_mode)
+    CONFIG, N_TOK, N_REG = args.config, args.tokens, args.regions
     cfg = BertConfig.from_json_file(os.path.join(ROOT, "vilbert-multi-task_amd", "config", CONFIG)).to_dict()
     B = args.batch
     if args.mode == "fwd":
@@ -255,6 +264,48 @@ def main():
                "note": "opt-in (--gemm-mode bf16x6 / VB_GEMM_MODE): same parity tests pass; GEMM ceiling 2500/6 = 417 TF"}
         _native.set_gemm_mode("f32")
 
+    # PCIe-inclusive leg (opt-in): raw worker-shaped numpy batches on the host -> pinned staging -> async H2D on
+    # a copy stream -> native batch finishing -> the same step. Reported beside `value`, never as `value`.
+    host_leg = None
+    if args.host_inputs and args.mode == "train" and world == 1:
+        import numpy as np
+        from vilbert.input_pipeline import DeviceBatchPipeline
+        g = np.random.RandomState(5)
+        raws = []
+        for _ in range(2):
+            ids = g.randint(0, cfg["vocab_size"], size=(B, N_TOK)).astype(np.int64)
+            lm = np.where(g.rand(B, N_TOK) < 0.15, ids, -1).astype(np.int64)
+            lm[:, 1] = ids[:, 1]
+            il = np.where(g.rand(B, N_REG) < 0.15, 1, -1).astype(np.int64)
+            il[:, 0] = 1
+            tgt = g.rand(B, N_REG, cfg["v_target_size"]).astype(np.float32)
+            tgt /= tgt.sum(-1, keepdims=True)
+            raws.append((ids, np.ones((B, N_TOK), np.int64), np.zeros((B, N_TOK), np.int64), lm,
+                         np.zeros(B, np.int64), g.rand(B, N_REG, cfg["v_feature_size"]).astype(np.float32) * 2,
+                         g.rand(B, N_REG, 5).astype(np.float32), tgt, il, np.ones((B, N_REG), np.int64),
+                         (il == 1).astype(np.int64)))
+        n_host = max(4, args.steps // 2)
+
+        def run(n):
+            for b in DeviceBatchPipeline((raws[i % 2] for i in range(n)), device, objective=1):
+                input_ids, input_mask, segment_ids, lm_label_ids, is_next, feat, loc, target, ilabel, imask = b
+                opt.zero_grad(set_to_none=True)
+                lm_l, img_l, nsp_l = model(input_ids, feat, loc, segment_ids, input_mask, imask, lm_label_ids, ilabel,
+                                           target, is_next)      # argument order of train_concap.py:542-553
+                (lm_l.mean() + img_l.mean() + nsp_l.mean()).backward()
+                opt.step()
+        run(2)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        run(n_host)
+        torch.cuda.synchronize()
+        host_ms = 1e3 * (time.perf_counter() - th) / n_host
+        mb = sum(a.nbytes for a in raws[0]) / 1e6
+        host_leg = {"value": round(B / (host_ms * 1e-3), 2), "unit": "samples/s", "ms_per_step": round(host_ms, 3),
+                    "steps": n_host, "host_mb_per_step": round(mb, 1),
+                    "note": "inputs start as numpy arrays on the host each step (pinned double-buffered H2D on a copy "
+                            "stream + vb_concap_finish_batch); PCIe-inclusive, not the headline"}
+
     # Roofline of the dominant kernel (the fp32-MFMA GEMM family, ~99 % of the FLOPs): every
     # vb_linear_fwd launch of extra profiled steps is bracketed with HIP events on the launch stream.
     prof_steps = 1 if args.mode == "train" else 2
@@ -296,8 +347,9 @@ def main():
             traffic_note = "rocprofv3 PMC, %s M=%d N=%d K=%d: %.0f MB per launch vs %.0f MB algorithmic (profiles/r01_gemm_traffic.json)" % (
                 t0["kernel"], t0["M"], t0["N"], t0["K"], traffic / 1e6, t0["algorithmic_bytes"] / 1e6)
         line = {
-            "metric": "samples/sec (36 regions, 36 tokens) ViLBERT-base 6L/6C %s" %
-                      ("forward" if args.mode == "fwd" else "fwd+bwd"),
+            "metric": "samples/sec (%d regions, %d tokens) ViLBERT-%s %s" %
+                      (N_REG, N_TOK, "base 6L/6C" if CONFIG == "bert_base_6layer_6conect.json" else CONFIG,
+                       "forward" if args.mode == "fwd" else "fwd+bwd"),
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -306,7 +358,7 @@ def main():
                                    (CONFIG, "forward-only (eval, no_grad), VILBertForVLTasks incl. all heads"
                                     if args.mode == "fwd" else
                                     "train_concap step: BertForMultiModalPreTraining fwd+bwd (dropout on) + "
-                                    "grad all-reduce + AdamW, 36 regions + 1 global row", B, N_TOK, n_reg),
+                                    "grad all-reduce + AdamW, %d regions + 1 global row" % N_REG, B, N_TOK, n_reg),
                        "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world,
                        "gflop_per_sample_model": round(mult * total_f / 1e9, 3),
@@ -327,6 +379,8 @@ def main():
         line["config"]["gemm_mode"] = args.gemm_mode
         if alt is not None:
             line["alt_gemm_mode"] = alt
+        if host_leg is not None:
+            line["host_inputs"] = host_leg
         if args.gemm_mode != "f32":
             peak = 2500.0 / (6 if args.gemm_mode == "bf16x6" else 3)
             line["roofline"].update(peak=round(peak, 1), frac=round(achieved / peak, 4),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 3
+#define VB_ABI_VERSION 4
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -295,6 +295,40 @@ int vb_kl_fwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_
 int vb_kl_bwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
               int64_t ldt, const float* lse, const float* tsum, const float* grad_loss, float divisor,
               float* dscores, int64_t ldd);
+
+/* ------------------------------------------------------------------------------------------
+ * vb_concap_finish_batch: device-side finishing of a Conceptual-Captions pre-training batch
+ * (SURVEY.md section 8(f) row f3).
+ *
+ * Replaces the per-step numpy work of ConceptCapLoaderTrain.__iter__ (reference
+ * vilbert/datasets/concept_cap_dataset.py:241-282: global mean-region feature row, its [0,0,1,1,1]
+ * box and mask entry are prepended) and the objective-1 label edit of the training loop
+ * (train_concap.py:535-540). Inputs are the worker's raw arrays copied to the device unchanged:
+ *   image_feat [B,R,F] f32, image_loc [B,R,5] f32, image_mask [B,R] i64, masked_label [B,R] i64,
+ *   is_next [B] i64, image_label [B,R] i64, lm_label_ids [B,T] i64.
+ * Outputs: out_image_feat [B,R+1,F] (row 0 = sum over the R rows / max(#(masked_label == 0), 1),
+ *   summed in fp32 in row order, divided in fp64 and rounded to fp32 like the reference's numpy
+ *   expression), out_image_loc [B,R+1,5], out_image_mask [B,R+1] i64, out_image_label [B,R],
+ *   out_lm_label_ids [B,T]; with objective == 1 both label tensors are multiplied by (is_next == 0) and
+ *   zeros become -1, otherwise they are copied. F % 4 == 0; feature pointers 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t batch, regions, tokens, feat_dim, objective;
+    const float* image_feat;
+    const float* image_loc;
+    const int64_t* image_mask;
+    const int64_t* masked_label;
+    const int64_t* is_next;
+    const int64_t* image_label;
+    const int64_t* lm_label_ids;
+    float* out_image_feat;
+    float* out_image_loc;
+    int64_t* out_image_mask;
+    int64_t* out_image_label;
+    int64_t* out_lm_label_ids;
+} vb_concap_batch;
+
+int vb_concap_finish_batch(void* stream, const vb_concap_batch* a);
 
 #ifdef __cplusplus
 }

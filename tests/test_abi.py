@@ -33,7 +33,7 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = ["vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
+EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd"]
 
 
@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 3
+    assert lib.vb_abi_version() == 4
     prev = native.set_gemm_mode("bf16x6")
     assert native.set_gemm_mode(prev) == "bf16x6" and native.set_gemm_mode(prev) == prev
     assert lib.vb_error_string(0) == b"ok"
@@ -64,7 +64,7 @@ def test_struct_layouts_match_the_header(native):
                            ("vb_attention_grads", native.AttentionGrads),
                            ("vb_linear_bwd_input_args", native.LinearBwdInputArgs),
                            ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs),
-                           ("vb_adamw_tensor", native.AdamWTensor)):
+                           ("vb_adamw_tensor", native.AdamWTensor), ("vb_concap_batch", native.ConcapBatch)):
         body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", text))[struct]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -84,6 +84,8 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.vb_layernorm_fwd(None, 0, 0, None, None, None, None, 0.0, None, None, None) == -1
     assert lib.vb_attention_bwd(None, None, None) == -1
     assert lib.vb_linear_bwd_input(None, None) == -1 and lib.vb_linear_bwd_weight(None, None) == -1
+    assert lib.vb_concap_finish_batch(None, None) == -1
+    assert lib.vb_xent_fwd(None, 1, 0, None, 0, None, -1, None, None, None, None) == -1
     assert lib.vb_layernorm_bwd_workspace(16, 768) == 4 * 2 * 768
     assert lib.vb_layernorm_bwd_workspace(17, 768) == 8 * 2 * 768
 

@@ -101,6 +101,19 @@ class AdamWTensor(ctypes.Structure):
     ]
 
 
+class ConcapBatch(ctypes.Structure):
+    """vb_concap_batch"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("regions", ctypes.c_int32), ("tokens", ctypes.c_int32),
+        ("feat_dim", ctypes.c_int32), ("objective", ctypes.c_int32),
+        ("image_feat", _c_f32p), ("image_loc", _c_f32p), ("image_mask", ctypes.c_void_p),
+        ("masked_label", ctypes.c_void_p), ("is_next", ctypes.c_void_p), ("image_label", ctypes.c_void_p),
+        ("lm_label_ids", ctypes.c_void_p),
+        ("out_image_feat", _c_f32p), ("out_image_loc", _c_f32p), ("out_image_mask", ctypes.c_void_p),
+        ("out_image_label", ctypes.c_void_p), ("out_lm_label_ids", ctypes.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/vilbert_hip.h one to one (checked by
 # tests/test_abi.py against the header text).
 _I32, _I64, _F32, _P, _U64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint64
@@ -128,6 +141,7 @@ SIGNATURES = {
     "vb_xent_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
     "vb_kl_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _F32, _P, _P, _P, _P]),
     "vb_kl_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _I64]),
+    "vb_concap_finish_batch": (ctypes.c_int, [_P, ctypes.POINTER(ConcapBatch)]),
 }
 
 _lib = None
@@ -145,7 +159,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 3:
+        if handle.vb_abi_version() != 4:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib
