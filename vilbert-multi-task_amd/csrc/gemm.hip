@@ -569,7 +569,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
         const int t = xcd_swizzle(b, p.n_big);
         const int m0 = (t / p.tiles_n) * 128, n0 = (t % p.tiles_n) * 128;
         // measured: the branch-free variant gains 10-18 % on wgrad (TN) and 1-4 % on dgrad (NN) but loses
-        // 2-14 % on the forward (NT) layout, whose predicated loads schedule better as they are
+        // 2-14 % on the forward (NT) layout (also with the prefetch pinned to the top of the step), whose
+        // predicated loads schedule better as they are
         if (!(A_KC && B_KC) && VEC && m0 + 128 <= p.M && n0 + 128 <= p.N && p.K % BK == 0)
             gemm_tile<2, 2, A_KC, B_KC, VEC, true>(p, smem, m0, n0);
         else gemm_tile<2, 2, A_KC, B_KC, VEC, false>(p, smem, m0, n0);
