@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 4
+#define VB_ABI_VERSION 5
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -90,9 +90,11 @@ typedef struct {
 int vb_linear_fwd(void* stream, const vb_linear_args* a);
 
 /* ------------------------------------------------------------------------------------------
- * vb_linear_bwd_input:  dX[M,K] (+)= dY[M, nseg*seg_n] . stack(W)
+ * vb_linear_bwd_input:  dX[M,K] (+)= dY[M, nseg*seg_n] . stack(W) + residual
  * Gradient of nn.Linear w.r.t. its input (autograd of the lines listed for vb_linear_fwd); the
  * stacked segments are contracted in one launch. accumulate != 0 adds into dX.
+ * residual (ldr, may be NULL): a gradient of the same shape arriving over a skip connection (the `+ x` of
+ * vilbert.py:516 and its twins), added in the epilogue instead of by a separate pass.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t M, K;
@@ -101,6 +103,7 @@ typedef struct {
     const float* W[VB_MAX_SEGMENTS]; int64_t ldw;
     float* dX;                 int64_t ldx;
     int32_t accumulate;
+    const float* residual;     int64_t ldr;
 } vb_linear_bwd_input_args;
 
 int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args* a);

@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 4
+    assert lib.vb_abi_version() == 5
     prev = native.set_gemm_mode("bf16x6")
     assert native.set_gemm_mode(prev) == "bf16x6" and native.set_gemm_mode(prev) == prev
     assert lib.vb_error_string(0) == b"ok"
@@ -100,3 +100,22 @@ def test_product_path_has_no_cpu_fallback(native):
         with torch.no_grad():
             model(x["input_ids"], x["image_feat"], x["image_loc"], x["token_type_ids"], x["attention_mask"],
                   x["image_attention_mask"])
+
+
+def test_gemm_kernels_keep_their_register_budget(native):
+    """Occupancy guard: the fp32 GEMM kernels must fit 4 waves per SIMD (<= 128 VGPRs), no kernel of the
+    library may spill to scratch (the build records hipcc's kernel-resource-usage remarks per source)."""
+    csrc = os.path.dirname(native.LIB_PATH)
+    seen = 0
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith(".resource.txt"):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        for fn, vgprs, scratch in re.findall(
+                r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", text, flags=re.S):
+            seen += 1
+            if "layernorm_bwd_kernelILi32" not in fn:   # the 2048-wide classifier LayerNorm (heads only) may spill
+                assert int(scratch) == 0, "%s spills %s bytes/lane" % (fn, scratch)
+            if "gemm_f32_kernel" in fn:
+                assert int(vgprs) <= 128, "%s uses %s VGPRs" % (fn, vgprs)
+    assert seen > 20

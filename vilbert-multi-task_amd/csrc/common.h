@@ -26,3 +26,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
     // vilbert.py:117  x * 0.5 * (1 + erf(x / sqrt(2)))
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
 }
+
+__device__ __forceinline__ float gelu_grad(float x) {
+    // d/dx [x * 0.5 * (1 + erf(x / sqrt 2))] = 0.5 (1 + erf(x / sqrt 2)) + x * exp(-x^2 / 2) / sqrt(2 pi)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}

@@ -6,12 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_grad(float x) {
-    // d/dx [x * 0.5 * (1 + erf(x / sqrt 2))] = 0.5 (1 + erf(x / sqrt 2)) + x * exp(-x^2 / 2) / sqrt(2 pi)
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
-
 template <int ACT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(long n4, const f32x4* __restrict__ dy,
                                                       const f32x4* __restrict__ pre, f32x4* __restrict__ dx) {

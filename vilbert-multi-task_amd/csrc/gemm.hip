@@ -674,6 +674,7 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
     // a K tile of the contraction (over out-features) must not straddle two weight segments; otherwise
     // run one launch per segment, accumulating.
     const bool fused = a->nseg == 1 || (a->seg_n % BK) == 0;
+    if (!fused && a->residual != nullptr) return VB_E_SEGMENT;
     const int launches = fused ? 1 : a->nseg;
     for (int l = 0; l < launches; ++l) {
         GemmP p{};
@@ -692,7 +693,9 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
         p.C[0] = a->dX; p.ldc = a->ldx; p.cseg = (p.M + 127) / 128 * 128;
         p.act = VB_ACT_NONE;
         p.accumulate = (a->accumulate || l > 0) ? 1 : 0;
-        p.epi = p.accumulate ? EPI_ACCUM : EPI_STORE;
+        p.R = a->residual; p.ldr = a->ldr;
+        if (p.R != nullptr) p.epi = p.accumulate ? EPI_GENERIC : EPI_RES;
+        else p.epi = p.accumulate ? EPI_ACCUM : EPI_STORE;
         p.ktiles_per_split = (p.K + BK - 1) / BK;
         if (int e = launch_gemm<true, false>(st, p, vec, 1)) return e;
     }

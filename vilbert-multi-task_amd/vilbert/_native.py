@@ -75,6 +75,7 @@ class LinearBwdInputArgs(ctypes.Structure):
         ("W", _c_f32p * VB_MAX_SEGMENTS), ("ldw", ctypes.c_int64),
         ("dX", _c_f32p), ("ldx", ctypes.c_int64),
         ("accumulate", ctypes.c_int32),
+        ("residual", _c_f32p), ("ldr", ctypes.c_int64),
     ]
 
 
@@ -159,7 +160,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 4:
+        if handle.vb_abi_version() != 5:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -60,6 +60,40 @@ class LinearFn(Function):
         return (dx, dres, None, None, None) + tuple(dws) + tuple(dbs)
 
 
+class FFNFn(Function):
+    """y = dropout(act(x @ W1.T + b1) @ W2.T + b2, p) + x - the feed-forward block in front of its LayerNorm
+    (reference vilbert.py:500-503 + :513-517 and the image / connection twins), as ONE autograd node.
+    Backward: the dgrad through W1 adds the skip-connection gradient in its GEMM epilogue (no torch add). (The
+    GELU backward stays a separate HBM-bound pass: folded into the dgrad epilogue its erf + exp per element
+    pushed the GEMM kernels from 128 to 256 VGPRs + scratch - measured -6 % on the whole step.)"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, drop_p):
+        seed = next_seed() if drop_p > 0.0 else 0
+        h, pre = ops.linear_fwd(x, [w1], [b1], act, None, want_preact=True)
+        y, _ = ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x, pre, h, w1, w2)
+        ctx.act, ctx.drop = act, (drop_p, seed)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, h, w1, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dyd = ops.dropout(dy, ctx.drop[0], ctx.drop[1]) if ctx.drop[0] > 0.0 else dy
+        inter, hidden = w1.shape[0], w1.shape[1]
+        dpre = ops.act_bwd(ops.linear_bwd_input(dyd, [w2], inter), pre, ctx.act)
+        dw2 = db2 = dw1 = db1 = dx = None
+        if ctx.needs_input_grad[3] or (ctx.has_bias[1] and ctx.needs_input_grad[4]):
+            (dw2,), (db2,) = ops.linear_bwd_weight(dyd, h, 1, w2.shape[0], [ctx.has_bias[1] and ctx.needs_input_grad[4]])
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_bwd_input(dpre, [w1], hidden, residual=dy).view(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
+            (dw1,), (db1,) = ops.linear_bwd_weight(dpre, x, 1, inter, [ctx.has_bias[0] and ctx.needs_input_grad[2]])
+        return dx, dw1, db1, dw2, db2, None, None
+
+
 class LayerNormFn(Function):
     """TF-style LayerNorm of one tensor."""
 

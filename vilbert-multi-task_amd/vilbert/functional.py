@@ -27,6 +27,15 @@ def linear(x, weights, biases=None, act=None, residual=None, drop_p=0.0):
     return ops.linear_fwd(x, weights, biases, act, residual, drop_p=drop_p, seed=seed)[0]
 
 
+def ffn(x, w1, b1, act, w2, b2, drop_p=0.0):
+    """dropout(act(x @ w1.T + b1) @ w2.T + b2, drop_p) + x  (the block in front of the output LayerNorm)."""
+    if _needs_grad(x, w1, b1, w2, b2):
+        return A.FFNFn.apply(x, w1, b1, w2, b2, act, drop_p)
+    h = ops.linear_fwd(x, [w1], [b1], act)[0]
+    seed = A.next_seed() if drop_p > 0.0 else 0
+    return ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)[0]
+
+
 def layer_norm(x, gamma, beta, eps=1e-12):
     if _needs_grad(x, gamma, beta):
         return A.LayerNormFn.apply(x, gamma, beta, eps)

@@ -103,8 +103,9 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     return y, pre
 
 
-def linear_bwd_input(dy, weights, in_features):
-    """dX = dY @ cat(weights) for dY [..., nseg*n]; returns [..., in_features]."""
+def linear_bwd_input(dy, weights, in_features, residual=None):
+    """dX = dY @ cat(weights) + residual for dY [..., nseg*n]; returns [..., in_features].
+    residual: a gradient of the same shape arriving over a skip connection (added in the GEMM epilogue)."""
     nseg, seg_n = len(weights), weights[0].shape[0]
     dy = _contig(dy)
     M = dy.numel() // (nseg * seg_n)
@@ -117,6 +118,11 @@ def linear_bwd_input(dy, weights, in_features):
     a.ldw = in_features
     a.dX, a.ldx = dx.data_ptr(), in_features
     a.accumulate = 0
+    if residual is not None:
+        residual = _contig(residual)
+        if residual.numel() != M * in_features:
+            raise RuntimeError("linear_bwd_input: residual shape mismatch")
+        a.residual, a.ldr = N.dev_f32(residual, "linear residual grad"), in_features
     _timed(lambda: N.check(N.lib().vb_linear_bwd_input(N.stream_ptr(), ctypes.byref(a)), "vb_linear_bwd_input"),
            2.0 * M * nseg * seg_n * in_features)
     return dx
@@ -124,7 +130,8 @@ def linear_bwd_input(dy, weights, in_features):
 
 def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
     """Per segment: dW_s = dY[:, s]^T @ X and db_s = colsum(dY[:, s]) in one call.
-    Returns (list dW, list db-or-None)."""
+    Returns (list dW, list db-or-None). The split-K kernel adds into its targets with atomics: all of a
+    call's gradients are slices of ONE zero-filled buffer (one fill launch instead of two per segment)."""
     dy = _contig(dy)
     K = x.shape[-1]
     x2, ldx, _ = _row_view(x, K)
@@ -133,11 +140,17 @@ def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
     a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
     a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), nseg * seg_n
     a.X, a.ldx = N.dev_f32(x2, "linear input"), ldx
-    a.ldw, a.accumulate = K, 0
-    dws, dbs = [], []
+    a.ldw, a.accumulate = K, 1
+    wsz, bsz = (seg_n * K + 3) // 4 * 4, (seg_n + 3) // 4 * 4          # every slice stays 16-byte aligned
+    flat = torch.zeros(nseg * wsz + sum(bsz for s in range(nseg) if want_bias[s]), dtype=torch.float32,
+                       device=dy.device)
+    dws, dbs, off = [], [], nseg * wsz
     for s in range(nseg):
-        dw = torch.empty(seg_n, K, dtype=torch.float32, device=dy.device)
-        db = torch.empty(seg_n, dtype=torch.float32, device=dy.device) if want_bias[s] else None
+        dw = flat[s * wsz:s * wsz + seg_n * K].view(seg_n, K)
+        db = None
+        if want_bias[s]:
+            db = flat[off:off + seg_n]
+            off += bsz
         a.dW[s] = dw.data_ptr()
         a.dbias[s] = db.data_ptr() if db is not None else None
         dws.append(dw)

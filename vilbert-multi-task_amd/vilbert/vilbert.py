@@ -250,6 +250,14 @@ def _dense_dropout_add_norm(dense, dropout, norm, hidden_states, input_tensor):
     return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor, drop_p=_drop_p(dropout)))
 
 
+def _ffn(intermediate, output, x):
+    """output(intermediate(x), x) = LayerNorm(dropout(dense2(act(dense1(x)))) + x) as one fused autograd node
+    + the LayerNorm (``intermediate`` / ``output`` are the reference-named modules that own the parameters)."""
+    y = F.ffn(x, intermediate.dense.weight, intermediate.dense.bias, intermediate.intermediate_act_fn,
+              output.dense.weight, output.dense.bias, _drop_p(output.dropout))
+    return output.LayerNorm(y)
+
+
 class _ResidualNormOutput(nn.Module):
     """LayerNorm(dropout(dense(h)) + input): BertSelfOutput / BertOutput / BertImageSelfOutput /
     BertImageOutput (reference vilbert.py:463-474, 506-517, 622-633, 667-678)."""
@@ -312,8 +320,7 @@ class BertLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask):
         attention_output, attention_probs = self.attention(hidden_states, attention_mask)
-        intermediate_output = self.intermediate(attention_output)
-        return self.output(intermediate_output, attention_output), attention_probs
+        return _ffn(self.intermediate, self.output, attention_output), attention_probs
 
 
 class BertImageSelfAttention(nn.Module):
@@ -395,8 +402,7 @@ class BertImageLayer(nn.Module):
     def forward(self, hidden_states, attention_mask, txt_embedding, txt_attention_mask):
         attention_output, attention_probs = self.attention(hidden_states, attention_mask, txt_embedding,
                                                            txt_attention_mask)
-        intermediate_output = self.intermediate(attention_output)
-        return self.output(intermediate_output, attention_output), attention_probs
+        return _ffn(self.intermediate, self.output, attention_output), attention_probs
 
 
 class BertBiAttention(nn.Module):
@@ -490,11 +496,11 @@ class BertConnectionLayer(nn.Module):
 
         def image_branch():
             a1 = _dense_dropout_add_norm(bo.dense1, bo.dropout1, bo.LayerNorm1, bi_output2, input_tensor1)
-            return self.v_output(self.v_intermediate(a1), a1)
+            return _ffn(self.v_intermediate, self.v_output, a1)
 
         def text_branch():
             a2 = _dense_dropout_add_norm(bo.dense2, bo.dropout2, bo.LayerNorm2, bi_output1, input_tensor2)
-            return self.t_output(self.t_intermediate(a2), a2)
+            return _ffn(self.t_intermediate, self.t_output, a2)
 
         layer_output1, layer_output2 = _concurrent(image_branch, text_branch, [bi_output2, input_tensor1])
         return layer_output1, layer_output2, co_attention_probs
