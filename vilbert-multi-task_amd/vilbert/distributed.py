@@ -37,7 +37,7 @@ class _Bucket(object):
 
     def reset(self):
         self.ready = set()
-        self.events = {}     # param index -> event recorded on the stream that produced its gradient
+        self.streams = {}    # raw stream handle -> stream on which some gradient of this bucket was produced
         self.work = None
         self.launched = False
 
@@ -99,10 +99,10 @@ class DistributedDataParallel(nn.Module):
             b.ready.add(i)
             if param.grad is not None and param.grad.is_cuda:
                 # the model runs its text / image streams on two HIP streams, so gradients of one bucket
-                # are produced on different streams: remember where, the packer waits for all of them
-                ev = torch.cuda.Event()
-                ev.record()
-                b.events[i] = ev
+                # are produced on different streams: remember which (no event per gradient - a stream is
+                # in-order, so waiting for the stream at pack time covers every gradient enqueued on it)
+                st = torch.cuda.current_stream(param.grad.device)
+                b.streams.setdefault(st.cuda_stream, st)
             if not self.delay_allreduce and self._never_used is not None and not b.launched \
                     and len(b.ready) >= b.expected:
                 self._launch(b)
@@ -110,10 +110,11 @@ class DistributedDataParallel(nn.Module):
 
     def _launch(self, b):
         """Pack the bucket (one multi-tensor copy; unused slices are zero) and start its all-reduce."""
-        if b.events:
+        if b.streams:
             cur = torch.cuda.current_stream()
-            for ev in b.events.values():
-                cur.wait_event(ev)
+            for handle, st in b.streams.items():
+                if handle != cur.cuda_stream:
+                    cur.wait_stream(st)
         src, dst = [], []
         for i, p in enumerate(b.params):
             if p.grad is not None and p.grad.data_ptr() != b.views[i].data_ptr():
