@@ -3,7 +3,9 @@
 //
 // ViLBERT sequences are short (36 tokens / 36 regions pre-training, <= 306 in the task table), so
 // this is not a flash-attention problem: one 64-lane wave owns a 16-row tile of one (sample, head)
-// and keeps the whole score row block in registers - no LDS, no S x S round trip through HBM, no
+// and keeps the whole score row block in registers - no S x S round trip through HBM. Two kernel families share the arithmetic: the generic one below (operands
+// straight from L2, any length <= 320 keys, batch broadcast) and an LDS-staged one for sequences of at
+// most 48 rows (one block per (sample, head), K / V or Q / dO staged once) further down. Neither makes
 // head split / merge copies (Q, K, V are read straight out of the fused [q | k | v] projection, O is
 // written token-major, the backward writes dQ/dK/dV straight into the fused gradient buffer).
 //
