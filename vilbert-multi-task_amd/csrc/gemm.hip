@@ -748,7 +748,8 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
         int splits = 1;
         {
             double best = -1.0;
-            for (int r = 4; r >= 2; --r) {
+            static const int rmax = [] { const char* e = getenv("VB_WGRAD_RMAX"); return e ? atoi(e) : 4; }();
+            for (int r = rmax; r >= 2; --r) {
                 int s = (256 * r) / tiles;
                 if (s < 1) s = 1;
                 if (s > kt_total / 4) s = kt_total / 4 > 0 ? kt_total / 4 : 1;  // >= 4 K tiles per block
