@@ -163,4 +163,31 @@ inline void plan_tiles(GemmP& p, int splits, bool planes_mode) {
     p.n_small = recut ? 4 * left : 0;
 }
 
+// Staging of one R x 16 operand tile into registers (R / 64 float4 per thread).
+// k-contiguous operand (global [rows][ld]): thread t owns rows (t >> 2) + 64 it and the four k values
+// 4 (t & 3) .. +3 of every K tile, so the row base pointers are computed once per block (this is also
+// where a row is mapped to its weight segment).
+template <bool VEC, int NLD>
+__device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[NLD], const float* const (&rowp)[NLD], int k, int K) {
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rowp[it] != nullptr) {
+            const float* g = rowp[it] + k;
+            if (VEC) {
+                if (k < K) v = *reinterpret_cast<const f32x4*>(g);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < K) v[e] = g[e];
+            }
+        }
+        reg[it] = v;
+    }
+}
+
+
+// bf16-planes kernels (gemm_planes.hip): launch for operand layouts (a_kc, b_kc), planes in {2, 3}
+int launch_gemm_planes(hipStream_t st, const GemmP& p, bool vec, int splits, int planes, bool a_kc, bool b_kc);
+
 }  // namespace vbgemm
