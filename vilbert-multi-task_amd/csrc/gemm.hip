@@ -274,7 +274,8 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
     dim3 grid(p.n_big + p.n_small, splits), block(256);
     if (planes != 0) {
         // operands split into bf16 planes on their way into LDS (gemm_planes.hip)
-        return launch_gemm_planes(st, p, vec, splits, planes, A_KC, B_KC);
+        return planes == 3 ? launch_gemm_planes3(st, p, vec, splits, A_KC, B_KC)
+                           : launch_gemm_planes2(st, p, vec, splits, A_KC, B_KC);
     } else {
         if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, GEMM_LDS_BYTES, st, p);
         else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, GEMM_LDS_BYTES, st, p);

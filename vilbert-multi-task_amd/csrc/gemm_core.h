@@ -187,7 +187,8 @@ __device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[NLD], const float* con
 }
 
 
-// bf16-planes kernels (gemm_planes.hip): launch for operand layouts (a_kc, b_kc), planes in {2, 3}
-int launch_gemm_planes(hipStream_t st, const GemmP& p, bool vec, int splits, int planes, bool a_kc, bool b_kc);
+// bf16-planes kernels (gemm_planes.hip, one object per plane count): launch for operand layouts (a_kc, b_kc)
+int launch_gemm_planes3(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);
+int launch_gemm_planes2(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);
 
 }  // namespace vbgemm

@@ -3,6 +3,10 @@
 // gemm_core.h); separate translation unit so the two kernel families compile in parallel.
 #include "gemm_core.h"
 
+#ifndef VB_NPL
+#error "compile with -DVB_NPL=3 (bf16x6) or -DVB_NPL=2 (bf16x3)"
+#endif
+
 namespace {
 
 using namespace vbgemm;
@@ -320,25 +324,23 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const GemmP p) {
 }
 
 template <bool A_KC, bool B_KC>
-int launch_planes(hipStream_t st, const GemmP& p, bool vec, int splits, int planes) {
+int launch_planes(hipStream_t st, const GemmP& p, bool vec, int splits) {
     dim3 grid(p.n_big + p.n_small, splits), block(256);
-    const int lds = 2 * 2 * planes * PL_PLANE;
-    if (planes == 3) {
-        if (vec) hipLaunchKernelGGL((gemm_planes_kernel<A_KC, B_KC, true, 3>), grid, block, lds, st, p);
-        else hipLaunchKernelGGL((gemm_planes_kernel<A_KC, B_KC, false, 3>), grid, block, lds, st, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((gemm_planes_kernel<A_KC, B_KC, true, 2>), grid, block, lds, st, p);
-        else hipLaunchKernelGGL((gemm_planes_kernel<A_KC, B_KC, false, 2>), grid, block, lds, st, p);
-    }
+    const int lds = 2 * 2 * VB_NPL * PL_PLANE;
+    if (vec) hipLaunchKernelGGL((gemm_planes_kernel<A_KC, B_KC, true, VB_NPL>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_planes_kernel<A_KC, B_KC, false, VB_NPL>), grid, block, lds, st, p);
     VB_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
-int vbgemm::launch_gemm_planes(hipStream_t st, const GemmP& p, bool vec, int splits, int planes, bool a_kc, bool b_kc) {
-    if (a_kc && b_kc) return launch_planes<true, true>(st, p, vec, splits, planes);
-    if (a_kc && !b_kc) return launch_planes<true, false>(st, p, vec, splits, planes);
-    if (!a_kc && !b_kc) return launch_planes<false, false>(st, p, vec, splits, planes);
+// one object per plane count (compiled twice, -DVB_NPL=3 and -DVB_NPL=2, so the two builds run in parallel)
+#define VB_CAT2(a, b) a##b
+#define VB_CAT(a, b) VB_CAT2(a, b)
+int vbgemm::VB_CAT(launch_gemm_planes, VB_NPL)(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc) {
+    if (a_kc && b_kc) return launch_planes<true, true>(st, p, vec, splits);
+    if (a_kc && !b_kc) return launch_planes<true, false>(st, p, vec, splits);
+    if (!a_kc && !b_kc) return launch_planes<false, false>(st, p, vec, splits);
     return VB_E_BADARG;
 }
