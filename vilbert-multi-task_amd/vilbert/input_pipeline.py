@@ -13,6 +13,7 @@ unpacks after its own ``.cuda()`` calls and label edit:
      image_label, image_mask)
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -88,17 +89,23 @@ class DeviceBatchPipeline(object):
     optionally followed by extra items such as image ids - what ``self.ds.get_data()`` yields inside the
     reference loader) and yield finished device batches (+ the extra items).
 
-    Batch i+1 is staged (numpy -> pinned memory, then an asynchronous H2D copy on a dedicated stream) right
-    after the caller has enqueued step i, so the PCIe transfer and most of the host memcpy run under step i.
+    Batch i+1 is staged on a dedicated stream right after the caller has enqueued step i, so the transfer runs
+    under step i. Two staging modes: "direct" (default; the runtime copies straight from the pageable numpy
+    memory) and "pinned" (numpy -> pinned buffer -> asynchronous DMA; on this platform the CPU's writes into
+    the pinned mapping are the slow part).
     (Staging from a background thread was measured and is slower: the step's ~1500 kernel launches are
     Python-side work and lose more to GIL hand-offs than the overlap wins - 161 vs 137 ms per step at batch
     256.) The id / mask / target tensors of a yielded batch alias the slot's device buffers: they stay valid
     until the caller asks for batch i + depth - 1 (do not keep them across iterations)."""
 
-    def __init__(self, source, device, objective=0, depth=2):
+    def __init__(self, source, device, objective=0, depth=2, staging=None):
         self.source, self.device, self.objective = source, torch.device(device), int(objective)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.slots = [_Slot() for _ in range(max(2, depth))]
+        # "pinned": numpy -> pinned host buffer -> asynchronous DMA.  "direct": hand the pageable numpy memory to
+        # the runtime's own copy path (it stages through its internal pinned chunks; blocks the host for the
+        # duration of the transfer but never makes the CPU write through an uncached host mapping).
+        self.staging = staging or os.environ.get("VB_PIPE_STAGING", "direct")   # measured: 131 vs 137-154 ms / step
 
     def _stage(self, slot, batch):
         if slot.copied is not None:
@@ -111,8 +118,11 @@ class DeviceBatchPipeline(object):
             for name in RAW_FIELDS:
                 arr = np.ascontiguousarray(fields[name])
                 h, d = slot.ensure(name, arr.shape, _DTYPES[name], self.device)
-                h.copy_(torch.from_numpy(arr))              # dtype conversion (e.g. int32 ids) happens here
-                d.copy_(h, non_blocking=True)
+                if self.staging == "direct" and arr.dtype == h.numpy().dtype:
+                    d.copy_(torch.from_numpy(arr), non_blocking=False)
+                else:
+                    h.copy_(torch.from_numpy(arr))          # dtype conversion (e.g. int32 ids) happens here
+                    d.copy_(h, non_blocking=True)
             slot.copied = torch.cuda.Event()
             slot.copied.record(self.copy_stream)
 
