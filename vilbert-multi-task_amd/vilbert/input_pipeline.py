@@ -135,7 +135,10 @@ class DeviceBatchPipeline(object):
         self._stage(self.slots[0], batch)
         while True:
             slot = self.slots[idx]
-            torch.cuda.current_stream(self.device).wait_event(slot.copied)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(slot.copied)
+            for t in slot.dev.values():
+                t.record_stream(cur)      # allocated on the copy stream, read by kernels of the compute stream
             out = finish_batch(slot.dev, self.objective)
             yield out + slot.extra
             slot.released = torch.cuda.Event()
