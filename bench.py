@@ -383,8 +383,9 @@ def main():
             line["host_inputs"] = host_leg
         if args.gemm_mode != "f32":
             peak = 2500.0 / (6 if args.gemm_mode == "bf16x6" else 3)
+            line["dtype"] = "f32 operands split into bf16 planes (%s), fp32 accumulate" % args.gemm_mode
             line["roofline"].update(peak=round(peak, 1), frac=round(achieved / peak, 4),
-                                    kernel="gemm_split_kernel (v_mfma_f32_32x32x16_bf16, %s)" % args.gemm_mode,
+                                    kernel="gemm_planes_kernel (v_mfma_f32_32x32x16_bf16, %s)" % args.gemm_mode,
                                     peak_note="bf16 dense MFMA peak 2500 TF / MFMA products per fp32 product")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.mode)
