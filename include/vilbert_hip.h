@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 5
+#define VB_ABI_VERSION 6
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -167,8 +167,12 @@ int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, const float* dy
  * row task_emb[task_ids[b]] is inserted at output position 1 (it receives no position / type
  * embedding) and the output has n_tok + 1 rows per sample. out: [batch, n_tok (+1), hidden].
  * presum (may be NULL) receives the pre-LayerNorm sum (saved for backward).
+ * vocab / n_types / n_tasks are the row counts of word_emb / type_emb / task_emb (type_vocab_size is 1 in
+ * roberta_base_6layer_6connect.json): an id outside its table contributes a zero row instead of reading
+ * past the allocation (the reference's nn.Embedding raises a device assert there).
  * ------------------------------------------------------------------------------------------ */
-int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden,
+int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, int32_t vocab,
+                         int32_t n_types, int32_t n_tasks,
                          const int64_t* ids, const int64_t* seg, int32_t pos_offset,
                          const float* word_emb, const float* pos_emb, const float* type_emb,
                          const int64_t* task_ids, const float* task_emb,
@@ -177,10 +181,12 @@ int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hid
 
 /* vb_text_embed_bwd: scatter-add (fp32 atomics) of dx [batch, n_tok (+1), hidden] - the gradient of
  * the pre-LayerNorm sum - into the ZERO-FILLED (or accumulating) tables dword / dpos / dtype / dtask.
- * Word row 0 is nn.Embedding's padding_idx (vilbert.py:330-332) and receives nothing. */
-int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, const int64_t* ids,
-                      const int64_t* seg, const int64_t* task_ids, const float* dx, float* dword,
-                      float* dpos, float* dtype, float* dtask);
+ * Word row 0 is nn.Embedding's padding_idx (vilbert.py:330-332) and receives nothing; ids outside
+ * [0, vocab) / [0, n_types) / [0, n_tasks) are skipped (dtype holds n_types rows - possibly one). */
+int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, int32_t vocab,
+                      int32_t n_types, int32_t n_tasks, const int64_t* ids, const int64_t* seg,
+                      const int64_t* task_ids, const float* dx, float* dword, float* dpos, float* dtype,
+                      float* dtask);
 
 /* ------------------------------------------------------------------------------------------
  * vb_image_embed_ln_fwd: LayerNorm(feat_proj + loc . Wloc^T + bloc)

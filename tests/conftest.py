@@ -12,6 +12,11 @@ for p in (PKG, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    config.addinivalue_line("markers", "slow: full-size (BASELINE.json batch) comparisons against the CPU oracle")
+    # the CPU oracle on a many-core host: torch's default of one thread per core (256 on the GPU box) is far
+    # slower than a few dozen threads for these matrix sizes (bench.py's cpu_baseline calibrates the same way)
+    import torch
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -51,6 +51,21 @@ CASES = {
                          batch=2, n_tok=36, n_reg=36,
                          stride={"vision_prediction": 16, "linguisic_prediction": 97,
                                  "vil_prediction": 3, "vil_prediction_gqa": 3}),
+    # BASELINE.json configs[2] shape: train_concap objective on the north-star model - 36 tokens, 36 regions + the
+    # global mean-region row (R = 37), loader label conventions; the three losses of the REAL reference
+    # (reference vilbert.py:1471-1597)
+    "base_6l6c_concap_losses_b4": dict(kind="pretraining", cfg=lambda: synth.load_config("bert_base_6layer_6conect.json"),
+                                       batch=4, n_tok=36, n_reg=37, labels=True),
+    # the same model's reference-shaped score tensors (no labels) at R = 37
+    "base_6l6c_concap_scores_b2": dict(kind="pretraining", cfg=lambda: synth.load_config("bert_base_6layer_6conect.json"),
+                                       batch=2, n_tok=36, n_reg=37,
+                                       stride={"prediction_scores_t": 97, "prediction_scores_v": 16}),
+    # BASELINE.json configs[3] model: bert_large_6layer_6conect.json (H = 1024, 16 heads x 64, I = 4096, 24 text
+    # layers, t_biattention_id = [18..23])
+    "large_6l6c_b2": dict(kind="vltasks", cfg=lambda: synth.load_config("bert_large_6layer_6conect.json"),
+                          batch=2, n_tok=36, n_reg=36,
+                          stride={"vision_prediction": 16, "linguisic_prediction": 97,
+                                  "vil_prediction": 3, "vil_prediction_gqa": 3}),
 }
 
 

@@ -1,11 +1,13 @@
 """Generate tests/golden/*.npz by running the REAL reference model (build container only).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case ...]      (no arguments = every case)
 
 Imports /root/reference/vilbert/vilbert.py through oracle/ref_loader.py (alias + import stubs), loads
 the seeded state dict from oracle/synth.py, runs the reference forward on CPU in eval mode and stores
 its outputs (fp32). Nothing under /root/reference is copied; only output tensors are saved.
 """
+import sys
+
 import numpy as np
 import torch
 
@@ -16,7 +18,10 @@ from oracle import ref_loader
 def main():
     ref = ref_loader.load()
     torch.set_grad_enabled(False)
+    only = sys.argv[1:]
     for case, c in cases.CASES.items():
+        if only and case not in only:
+            continue
         cfg, sd, x = cases.case_inputs(case)
         rc = ref.BertConfig.from_dict(cfg)
         model = ref.VILBertForVLTasks(rc, num_labels=1) if c["kind"] == "vltasks" \

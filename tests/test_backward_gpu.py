@@ -205,7 +205,8 @@ NO_DROPOUT = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, v_h
 
 
 @pytest.mark.parametrize("kind", ["pretraining", "vltasks"])
-@pytest.mark.parametrize("over", [{}, {"task_specific_tokens": True}, {"dynamic_attention": True, "fusion_method": "sum"}])
+@pytest.mark.parametrize("over", [{}, {"task_specific_tokens": True}, {"dynamic_attention": True, "fusion_method": "sum"},
+                                  {"model": "roberta", "type_vocab_size": 1}])   # roberta_base_6layer_6connect.json
 def test_model_gradients_match_oracle_autograd(kind, over):
     if kind == "pretraining" and over.get("task_specific_tokens"):
         pytest.skip("the pre-training wrapper does not pass task ids (reference vilbert.py:1486-1495)")
@@ -232,6 +233,33 @@ def test_model_gradients_base_2l2c():
     V._drop_p = lambda m: 0.0
     try:
         assert _grad_parity(cfg, "pretraining", 4, 20, 37) <= 1.0
+    finally:
+        V._drop_p = orig
+
+
+@pytest.mark.parametrize("cfgname,batch", [("bert_base_6layer_6conect.json", 4), ("bert_large_6layer_6conect.json", 2)])
+def test_model_gradients_north_star_configs(cfgname, batch):
+    """Every parameter gradient of the train_concap objective (T = 36, R = 36 + 1 global row, loader label
+    conventions) against autograd through the CPU oracle, on the north-star model (BASELINE.json configs[1-2])
+    and on bert_large_6layer_6conect (configs[3]: H = 1024, 16 x 64 heads, I = 4096, 24 text layers)."""
+    import vilbert.vilbert as V
+    cfg = dict(synth.load_config(cfgname), **NO_DROPOUT)
+    orig = V._drop_p
+    V._drop_p = lambda m: 0.0
+    try:
+        assert _grad_parity(cfg, "pretraining", batch, 36, 37) <= 1.0
+    finally:
+        V._drop_p = orig
+
+
+def test_model_gradients_large_vltasks():
+    """bert_large multi-task wrapper (BASELINE.json configs[3]): gradients of a loss over every head."""
+    import vilbert.vilbert as V
+    cfg = dict(synth.load_config("bert_large_6layer_6conect.json"), **NO_DROPOUT)
+    orig = V._drop_p
+    V._drop_p = lambda m: 0.0
+    try:
+        assert _grad_parity(cfg, "vltasks", 2, 24, 101) <= 1.0      # real task shape: T = 23 + task token, R = 101
     finally:
         V._drop_p = orig
 

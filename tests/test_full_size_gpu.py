@@ -1,5 +1,6 @@
 """Parity at BASELINE.json's full single-GPU size (bert_base_6layer_6conect, batch 256, 36 tokens x 36 regions)
-through size-independent properties - the oracle cannot run this size in test time, so:
+- every row of every output against the CPU oracle (test_full_size_forward_all_rows_match_oracle, ~10 s of host
+time), and through size-independent properties:
   * samples 0-1 of the batch ARE the golden case base_6l6c_b2 (outputs of the real reference): the encoder is
     per-sample independent, so their rows of the batch-256 outputs must match the golden vectors at the 1e-4 bar
     (different GEMM tiling: M = 9216 rows, hybrid tail, all 256 CUs);
@@ -49,6 +50,25 @@ def test_full_size_forward_rows_match_golden_and_batch_permutation():
         for i, n in enumerate(cases.VL_NAMES):
             s = shift // 2 if n == "vil_binary_prediction" else shift
             helpers.assert_close(out2[i], out[i].roll(s, 0), "rolled / " + n, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.slow
+def test_full_size_forward_all_rows_match_oracle():
+    """BASELINE.json configs[1] in full: bert_base_6layer_6conect forward, batch 256, 36 x 36, ragged masks -
+    ALL 256 rows of all nine VILBertForVLTasks outputs against oracle/vilbert_oracle.py at the 1e-4 bar."""
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    from oracle import vilbert_oracle as vo
+    cfg, sd, x = _batch()
+    model = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    model.load_state_dict(sd, strict=True)
+    model = model.eval().to(DEV)
+    with torch.no_grad():
+        out = model(*helpers.to_device(_args(x), DEV))
+        for lo in range(0, B, 64):           # the oracle in four chunks (its [64, 36, 30522] logits are 0.28 GB each)
+            want = vo.vltasks_forward(sd, cfg, *(a[lo:lo + 64] for a in _args(x)))
+            for i, n in enumerate(cases.VL_NAMES):
+                rows = slice(lo // 2, (lo + 64) // 2) if n == "vil_binary_prediction" else slice(lo, lo + 64)
+                helpers.assert_close(out[i][rows], want[i], "B=256 rows %d.. / %s" % (lo, n))
 
 
 def test_full_size_backward_is_additive_over_the_batch():

@@ -147,6 +147,56 @@ def test_text_embedding(ops, task):
     _close(out, _ln64(e, g.double(), b.double()))
 
 
+def test_text_embedding_single_type_row_and_out_of_range_ids(ops):
+    """type_vocab_size = 1 (roberta_base_6layer_6connect.json): the backward must not touch a second type row;
+    ids outside their table read / write nothing (no access past the allocations)."""
+    B, T, H, V = 4, 7, 64, 30
+    g0 = torch.Generator().manual_seed(8)
+    ids = torch.randint(1, V, (B, T), generator=g0)
+    seg = torch.zeros(B, T, dtype=torch.long)
+    word, pos, typ = _rand(V, H, seed=1), _rand(16, H, seed=2), _rand(1, H, seed=3)
+    g, b = 1 + 0.1 * _rand(H, seed=5), 0.1 * _rand(H, seed=6)
+    dx = _rand(B, T, H, seed=9)
+    # the gradient tables sit inside one allocation with NaN canaries right behind each of them
+    pool = torch.full((V * H + 16 * H + H + 3 * H,), float("nan")).cuda()
+    dword, dpos, dtype = pool[:V * H].view(V, H), pool[V * H + H:V * H + 17 * H].view(16, H), \
+        pool[V * H + 18 * H:V * H + 19 * H].view(1, H)
+    for t in (dword, dpos, dtype):
+        t.zero_()
+    from vilbert import _native as N
+    ids_d, seg_d, dx_d = ids.cuda(), seg.cuda(), dx.cuda()       # (kept alive across the raw C-ABI call)
+    N.check(N.lib().vb_text_embed_bwd(N.stream_ptr(), B, T, H, V, 1, 0, ids_d.data_ptr(), seg_d.data_ptr(),
+                                      None, dx_d.data_ptr(), dword.data_ptr(), dpos.data_ptr(), dtype.data_ptr(),
+                                      None), "vb_text_embed_bwd")
+    torch.cuda.synchronize()
+    want_w = torch.zeros(V, H, dtype=torch.float64).index_add_(0, ids.reshape(-1), dx.double().reshape(-1, H))
+    _close(dword, want_w)
+    _close(dpos[:T], dx.double().sum(0))
+    _close(dtype, dx.double().sum((0, 1))[None])
+    canaries = torch.cat([pool[V * H:V * H + H], pool[V * H + 17 * H:V * H + 18 * H], pool[V * H + 19 * H:]])
+    assert torch.isnan(canaries).all(), "the backward wrote past a gradient table"
+    # forward + backward with ids / types / labels outside their tables: zero rows, nothing out of bounds
+    bad_ids, bad_seg = ids.clone(), seg.clone()
+    bad_ids[0, 1], bad_ids[1, 2], bad_seg[2, 3] = V + 5, -3, 1
+    out = ops.text_embed_ln_fwd(bad_ids.cuda(), bad_seg.cuda(), word.cuda(), pos.cuda(), typ.cuda(), g.cuda(), b.cuda(),
+                                1e-12)[0]
+    ok_w = ((bad_ids >= 0) & (bad_ids < V)).double()[..., None]
+    e = word.double()[bad_ids.clamp(0, V - 1)] * ok_w + pos.double()[torch.arange(T)][None] \
+        + typ.double()[bad_seg.clamp(0, 0)] * (bad_seg == 0).double()[..., None]
+    _close(out, _ln64(e, g.double(), b.double()))
+    dw, dp, dt, _ = ops.text_embed_bwd(dx.cuda(), bad_ids.cuda(), bad_seg.cuda(), None, (V, H), (16, H), (1, H), None)
+    assert torch.isfinite(dw).all() and torch.isfinite(dt).all()
+
+
+def test_cross_entropy_out_of_range_label_poisons_the_loss():
+    from vilbert import ops as O
+    logits = _rand(6, 11, seed=2).cuda()
+    labels = torch.tensor([1, -1, 11, 3, -1, 2]).cuda()         # 11 is outside [0, 11)
+    loss, lse, count = O.xent_fwd(logits, labels, -1)
+    assert torch.isnan(loss)                                      # loud, and no read past the row
+    assert torch.isfinite(O.xent_bwd(torch.ones(1).cuda(), logits, labels, -1, lse, count)).all()
+
+
 def test_image_embedding(ops):
     B, R, H = 4, 9, 1024
     proj, loc = _rand(B, R, H, seed=1), torch.rand(B, R, 5, generator=torch.Generator().manual_seed(2))

@@ -66,3 +66,22 @@ def test_native_adamw_matches_oracle(correct_bias):
         assert err <= 2e-6 * max(1.0, r.abs().max().item()), (s, err)
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.gpu
+def test_native_adamw_handles_misaligned_views():
+    """Parameters / gradients that are views at an odd element offset (not 16-byte aligned) take the scalar loop."""
+    from vilbert.optim import AdamW
+    g0 = torch.Generator().manual_seed(11)
+    n = 4099
+    base_p, base_g = torch.randn(n + 1, generator=g0).cuda(), torch.randn(n + 1, generator=g0).cuda() * 0.1
+    p = torch.nn.Parameter(base_p[1:])                  # data_ptr % 16 == 4
+    assert p.data_ptr() % 16 != 0
+    ref_p, ref_g = base_p[1:].cpu().clone(), base_g[1:].cpu().clone()
+    opt = AdamW([p], lr=1e-2, weight_decay=0.01)
+    ref_m, ref_v = torch.zeros_like(ref_p), torch.zeros_like(ref_p)
+    for step in range(1, 4):
+        p.grad = base_g[1:]
+        opt.step()
+        ao.adamw_step(ref_p, ref_g, ref_m, ref_v, step, 1e-2, (0.9, 0.999), 1e-6, 0.01, True)
+    assert (p.detach().cpu() - ref_p).abs().max().item() <= 2e-6 * ref_p.abs().max().item()

@@ -53,7 +53,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void xent_fwd_kernel(int n, const flo
     const float lse = row_lse(x, n, scratch);
     if (threadIdx.x == 0) {
         lse_out[r] = lse;
-        row_loss[r] = lse - x[lab];
+        // a label outside [0, n) (the reference's CrossEntropyLoss raises a device assert) poisons the loss
+        // with NaN instead of reading past the row
+        row_loss[r] = (lab >= 0 && lab < n) ? lse - x[lab] : NAN;
     }
 }
 

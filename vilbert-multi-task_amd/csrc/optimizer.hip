@@ -21,7 +21,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const vb_adamw_tensor* __res
     const float* __restrict__ g = t.grad;
     float* __restrict__ m = t.exp_avg;
     float* __restrict__ v = t.exp_avg_sq;
-    const long n4 = (end - off) >> 2;
+    // 16-byte accesses need all four base pointers 16-byte aligned (chunk offsets are multiples of 4 elements);
+    // a tensor that is an oddly offset view takes the scalar loop for its whole chunk
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                          reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    const long n4 = vec_ok ? (end - off) >> 2 : 0;
     for (long i = threadIdx.x; i < n4; i += 256) {
         const long e = off + 4 * i;
         f32x4 pp = *reinterpret_cast<f32x4*>(p + e);

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(long rows, int n_cols, c
 
 // reference vilbert.py:346-367
 template <int NV>
-__global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, int hidden,
-                                                         const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, int hidden, int vocab, int n_types,
+                                                         int n_tasks, const int64_t* __restrict__ ids,
                                                          const int64_t* __restrict__ seg, int pos_offset,
                                                          const float* __restrict__ word,
                                                          const float* __restrict__ pos,
@@ -103,13 +103,17 @@ __global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, i
     // with task tokens: output 0 <- token 0, output 1 <- task embedding, output t <- token t - 1
     const bool is_task = task_ids != nullptr && t_out == 1;
     const int t = (task_ids != nullptr && t_out >= 2) ? t_out - 1 : t_out;
+    // ids outside their table (the reference's nn.Embedding raises a device assert there) read nothing: the
+    // row contributes zeros instead of whatever lies past the allocation
     const float *w = nullptr, *pp = nullptr, *ty = nullptr;
     if (is_task) {
-        w = task_emb + task_ids[b] * hidden;
+        const int64_t k = task_ids[b];
+        if (k >= 0 && k < n_tasks) w = task_emb + k * hidden;
     } else {
-        w = word + ids[(long)b * n_tok + t] * hidden;
+        const int64_t id = ids[(long)b * n_tok + t], sg = seg[(long)b * n_tok + t];
+        if (id >= 0 && id < vocab) w = word + id * hidden;
         pp = pos + (long)(t + pos_offset) * hidden;
-        ty = type + seg[(long)b * n_tok + t] * hidden;
+        if (sg >= 0 && sg < n_types) ty = type + sg * hidden;
     }
     f32x4 v[NV];
 #pragma unroll
@@ -117,11 +121,11 @@ __global__ __launch_bounds__(256) void text_embed_kernel(int batch, int n_tok, i
         const int col = (i * 64 + lane) * 4;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (col < hidden) {
-            v[i] = *reinterpret_cast<const f32x4*>(w + col);
+            if (w != nullptr) v[i] = *reinterpret_cast<const f32x4*>(w + col);
             if (!is_task) {
                 // words + position + token_type, in the reference's order (vilbert.py:355)
                 v[i] += *reinterpret_cast<const f32x4*>(pp + col);
-                v[i] += *reinterpret_cast<const f32x4*>(ty + col);
+                if (ty != nullptr) v[i] += *reinterpret_cast<const f32x4*>(ty + col);
             }
         }
     }
@@ -214,16 +218,18 @@ extern "C" int vb_layernorm_fwd(void* stream, int64_t rows, int32_t n_cols, cons
     return 0;
 }
 
-extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden,
+extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, int32_t vocab,
+                                    int32_t n_types, int32_t n_tasks,
                                     const int64_t* ids, const int64_t* seg, int32_t pos_offset,
                                     const float* word_emb, const float* pos_emb, const float* type_emb,
                                     const int64_t* task_ids, const float* task_emb, const float* gamma,
                                     const float* beta, float eps, float* out, float* mean, float* rstd,
                                     float* presum) {
     if (ids == nullptr || seg == nullptr || word_emb == nullptr || pos_emb == nullptr || type_emb == nullptr ||
-        gamma == nullptr || beta == nullptr || out == nullptr || batch <= 0 || n_tok <= 0)
+        gamma == nullptr || beta == nullptr || out == nullptr || batch <= 0 || n_tok <= 0 || vocab <= 0 ||
+        n_types <= 0)
         return VB_E_BADARG;
-    if (task_ids != nullptr && task_emb == nullptr) return VB_E_BADARG;
+    if (task_ids != nullptr && (task_emb == nullptr || n_tasks <= 0)) return VB_E_BADARG;
     if (int e = check_cols(hidden)) return e;
     if (!vb_aligned16(word_emb) || !vb_aligned16(pos_emb) || !vb_aligned16(type_emb) || !vb_aligned16(out) ||
         !vb_aligned16(gamma) || !vb_aligned16(beta) || (task_emb != nullptr && !vb_aligned16(task_emb)))
@@ -232,7 +238,8 @@ extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, 
     const long rows = (long)batch * (n_tok + (task_ids != nullptr ? 1 : 0));
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
     VB_NV_DISPATCH(nv_for(hidden),
-                   hipLaunchKernelGGL((text_embed_kernel<NV>), grid, block, 0, st, batch, n_tok, hidden, ids, seg,
+                   hipLaunchKernelGGL((text_embed_kernel<NV>), grid, block, 0, st, batch, n_tok, hidden, vocab, n_types,
+                                      n_tasks, ids, seg,
                                       pos_offset, word_emb, pos_emb, type_emb, task_ids, task_emb, gamma, beta,
                                       eps, out, mean, rstd, presum));
     VB_LAUNCH_CHECK();
@@ -390,8 +397,8 @@ __global__ __launch_bounds__(1024) void colreduce_kernel(long parts, int width, 
 // Scatter-add of embedding-row gradients (fp32 atomics into the zero-filled tables).
 // reference vilbert.py:353-362 backward; word row 0 is padding_idx (no gradient from the gather).
 template <int NV>
-__global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int n_tok, int hidden,
-                                                                 const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int n_tok, int hidden, int vocab,
+                                                                 int n_tasks, const int64_t* __restrict__ ids,
                                                                  const int64_t* __restrict__ seg,
                                                                  const int64_t* __restrict__ task_ids,
                                                                  const float* __restrict__ dx,
@@ -406,10 +413,11 @@ __global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int 
     const int t = (task_ids != nullptr && t_out >= 2) ? t_out - 1 : t_out;
     float* w = nullptr;
     if (is_task) {
-        w = dtask + task_ids[b] * hidden;
+        const int64_t k = task_ids[b];
+        w = (k >= 0 && k < n_tasks) ? dtask + k * hidden : nullptr;
     } else {
         const int64_t id = ids[(long)b * n_tok + t];
-        w = id != 0 ? dword + id * hidden : nullptr;
+        w = (id > 0 && id < vocab) ? dword + id * hidden : nullptr;
         // position / token-type rows are shared by every sample (36 + 2 rows for 9216 tokens): they are
         // reduced by pos_type_grad_kernel instead of 9216-way contended atomics
     }
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256) void text_embed_scatter_kernel(int batch, int 
 
 // dpos[t] += sum_b dx[b, t] and dtype[s] += sum over the tokens of type s: one block per token
 // position walks the batch (coalesced rows), so dpos needs no atomics and dtype one per position.
-__global__ __launch_bounds__(256) void pos_type_grad_kernel(int batch, int n_tok, int hidden,
+__global__ __launch_bounds__(256) void pos_type_grad_kernel(int batch, int n_tok, int hidden, int n_types,
                                                             const int64_t* __restrict__ seg,
                                                             const int64_t* __restrict__ task_ids,
                                                             const float* __restrict__ dx,
@@ -444,16 +452,17 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(int batch, int n_tok
             ap += d;
             if (ty == 0) a0 += d;
             else if (ty == 1) a1 += d;
-            else {
+            else if (ty > 1 && ty < n_types) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dtype + ty * hidden + col + e, d[e]);
             }
         }
+        // the type table may hold a single row (roberta_base_6layer_6connect.json: type_vocab_size = 1)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             unsafeAtomicAdd(dpos + (long)t * hidden + col + e, ap[e]);
-            unsafeAtomicAdd(dtype + col + e, a0[e]);
-            unsafeAtomicAdd(dtype + hidden + col + e, a1[e]);
+            if (n_types > 0) unsafeAtomicAdd(dtype + col + e, a0[e]);
+            if (n_types > 1) unsafeAtomicAdd(dtype + hidden + col + e, a1[e]);
         }
     }
 }
@@ -490,24 +499,25 @@ extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, cons
     return 0;
 }
 
-extern "C" int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, const int64_t* ids,
-                                 const int64_t* seg, const int64_t* task_ids, const float* dx, float* dword,
-                                 float* dpos, float* dtype, float* dtask) {
+extern "C" int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, int32_t vocab,
+                                 int32_t n_types, int32_t n_tasks, const int64_t* ids, const int64_t* seg,
+                                 const int64_t* task_ids, const float* dx, float* dword, float* dpos, float* dtype,
+                                 float* dtask) {
     if (ids == nullptr || seg == nullptr || dx == nullptr || dword == nullptr || dpos == nullptr ||
-        dtype == nullptr || batch <= 0 || n_tok <= 0)
+        dtype == nullptr || batch <= 0 || n_tok <= 0 || vocab <= 0 || n_types <= 0)
         return VB_E_BADARG;
-    if (task_ids != nullptr && dtask == nullptr) return VB_E_BADARG;
+    if (task_ids != nullptr && (dtask == nullptr || n_tasks <= 0)) return VB_E_BADARG;
     if (int e = check_cols(hidden)) return e;
     if (!vb_aligned16(dx)) return VB_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long rows = (long)batch * (n_tok + (task_ids != nullptr ? 1 : 0));
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
     VB_NV_DISPATCH(nv_for(hidden), hipLaunchKernelGGL((text_embed_scatter_kernel<NV>), grid, block, 0, st, batch,
-                                                      n_tok, hidden, ids, seg, task_ids, dx, dword, dpos, dtype,
-                                                      dtask));
+                                                      n_tok, hidden, vocab, n_tasks, ids, seg, task_ids, dx, dword, dpos,
+                                                      dtype, dtask));
     VB_LAUNCH_CHECK();
     hipLaunchKernelGGL(pos_type_grad_kernel, dim3((unsigned)(n_tok + (task_ids != nullptr ? 1 : 0))), dim3(256), 0,
-                       st, batch, n_tok, hidden, seg, task_ids, dx, dpos, dtype);
+                       st, batch, n_tok, hidden, n_types, seg, task_ids, dx, dpos, dtype);
     VB_LAUNCH_CHECK();
     return 0;
 }

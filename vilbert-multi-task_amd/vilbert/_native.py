@@ -130,9 +130,9 @@ SIGNATURES = {
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
     "vb_layernorm_bwd_workspace": (ctypes.c_int64, [_I64, _I32]),
     "vb_layernorm_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "vb_text_embed_ln_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
+    "vb_text_embed_ln_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
                                              _F32, _P, _P, _P, _P]),
-    "vb_text_embed_bwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vb_text_embed_bwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vb_image_embed_ln_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _F32, _P, _P, _P, _P]),
     "vb_additive_mask": (ctypes.c_int, [_P, _I64, _P, _I32, _P]),
     "vb_attention_fwd": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs)]),
@@ -160,7 +160,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 5:
+        if handle.vb_abi_version() != 6:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib

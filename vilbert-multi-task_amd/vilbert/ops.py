@@ -235,8 +235,8 @@ def text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None,
         if task_ids.numel() != B:
             raise RuntimeError("task_ids must hold one id per sample")
     N.check(N.lib().vb_text_embed_ln_fwd(
-        N.stream_ptr(), B, T, H, N.dev_i64(ids, "input_ids"), N.dev_i64(seg, "token_type_ids"), 0,
-        N.dev_f32(word, "word_embeddings"), N.dev_f32(pos, "position_embeddings"),
+        N.stream_ptr(), B, T, H, word.shape[0], typ.shape[0], task_emb.shape[0] if task_emb is not None else 0,
+        N.dev_i64(ids, "input_ids"), N.dev_i64(seg, "token_type_ids"), 0, N.dev_f32(word, "word_embeddings"), N.dev_f32(pos, "position_embeddings"),
         N.dev_f32(typ, "token_type_embeddings"), N.dev_i64(task_ids, "task_ids"),
         N.dev_f32(task_emb, "task_embeddings"), N.dev_f32(gamma, "LayerNorm.weight"),
         N.dev_f32(beta, "LayerNorm.bias"), eps, out.data_ptr(),
@@ -258,7 +258,8 @@ def text_embed_bwd(dx, ids, seg, task_ids, word_shape, pos_shape, type_shape, ta
     if task_ids is not None:
         task_ids = _contig(task_ids.view(-1))
     N.check(N.lib().vb_text_embed_bwd(
-        N.stream_ptr(), B, T, word_shape[1], N.dev_i64(ids, "input_ids"), N.dev_i64(seg, "token_type_ids"),
+        N.stream_ptr(), B, T, word_shape[1], word_shape[0], type_shape[0], task_shape[0] if task_shape else 0,
+        N.dev_i64(ids, "input_ids"), N.dev_i64(seg, "token_type_ids"),
         N.dev_i64(task_ids, "task_ids"), N.dev_f32(dx, "embedding grad"), dword.data_ptr(), dpos.data_ptr(),
         dtype.data_ptr(), dtask.data_ptr() if dtask is not None else None), "vb_text_embed_bwd")
     return dword, dpos, dtype, dtask
