@@ -72,6 +72,10 @@ int vb_set_gemm_mode(int planes);
  * the residual is added (the `dropout(dense(x)) + input_tensor` of :471-473, 514-516, ...): keep mask =
  * f(seed, row * N + col), the same function vb_dropout uses, so vb_dropout(dY, seed) is its backward
  * (C must be contiguous, ldc == N, in that case).
+ * act_grad (ldg) may be NULL; when given it receives act'(A.W^T + bias), the derivative of the epilogue
+ * activation (gelu: 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi); relu: x > 0) - saved by the
+ * training forward so that the backward of `act` is ONE multiply in the epilogue of vb_linear_bwd_input
+ * (its `mul` argument) instead of a separate erf / exp pass over [M, N].
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t M, K;
@@ -82,6 +86,7 @@ typedef struct {
     float* C;                  int64_t ldc;
     const float* residual;     int64_t ldr;
     float* preact;             int64_t ldp;
+    float* act_grad;           int64_t ldg;
     int32_t act;
     float dropout_p;
     uint64_t seed;
@@ -95,6 +100,8 @@ int vb_linear_fwd(void* stream, const vb_linear_args* a);
  * stacked segments are contracted in one launch. accumulate != 0 adds into dX.
  * residual (ldr, may be NULL): a gradient of the same shape arriving over a skip connection (the `+ x` of
  * vilbert.py:516 and its twins), added in the epilogue instead of by a separate pass.
+ * mul (ldm, may be NULL): [M, K] elementwise multiplier of the result, dX = (dY . stack(W) + residual) * mul -
+ * the act_grad saved by the forward of the Linear that PRODUCED this layer's input (gelu backward fused here).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t M, K;
@@ -104,6 +111,7 @@ typedef struct {
     float* dX;                 int64_t ldx;
     int32_t accumulate;
     const float* residual;     int64_t ldr;
+    const float* mul;          int64_t ldm;
 } vb_linear_bwd_input_args;
 
 int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args* a);

@@ -1,0 +1,163 @@
+// Stand-alone GEMM laboratory: times (and checks) the three vb_linear_* entry points of libvilbert_hip.so on the
+// model's shapes without Python. Build + run (GPU box):
+//     make -C tools gemm_lab && [VB_GEMM_V2=0|1] [VB_GEMM_TILE=33|34|43|44|22] [VB_GEMM_ABL=1|2] tools/gemm_lab [quick|check]
+// Prints one line per shape: kind, M, N, K, nseg, microseconds, TFLOP/s (algorithmic 2MNK), max relative error
+// against an fp64-accumulating reference kernel.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../include/vilbert_hip.h"
+
+#define CK(x)                                                                         \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+__global__ void fill_kernel(float* p, long n, uint32_t seed, float scale) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)(i * 2654435761u) ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = ((float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f) * 2.0f * scale;
+}
+
+// C[m][n] = sum_k A(m,k) B(n,k) with generic strides (fp64 accumulate); sampled rows only
+__global__ void ref_kernel(int M, int N, int K, const float* A, long a_rs, long a_cs, const float* B, long b_rs, long b_cs,
+                           double* C, int row_step) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y * row_step;
+    if (n >= N || m >= M) return;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s += (double)A[m * a_rs + k * a_cs] * (double)B[n * b_rs + k * b_cs];
+    C[(long)blockIdx.y * N + n] = s;
+}
+
+static float* dev_rand(long n, uint32_t seed, float scale) {
+    float* p;
+    CK(hipMalloc(&p, n * sizeof(float)));
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, n, seed, scale);
+    return p;
+}
+
+template <class F>
+static double time_us(F fn, int iters) {
+    for (int i = 0; i < 3; ++i) fn();
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3 / iters;
+}
+
+// compares sampled rows of C (row-major [M, N], ld) against the fp64 reference
+static double check(int M, int N, int K, const float* A, long a_rs, long a_cs, const float* B, long b_rs, long b_cs,
+                    const float* C, long ldc, const float* bias) {
+    const int row_step = M > 64 ? M / 61 : 1;
+    const int rows = (M + row_step - 1) / row_step;
+    double* ref;
+    CK(hipMalloc(&ref, (size_t)rows * N * sizeof(double)));
+    hipLaunchKernelGGL(ref_kernel, dim3((N + 127) / 128, rows), dim3(128), 0, 0, M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, ref,
+                       row_step);
+    std::vector<double> h((size_t)rows * N);
+    std::vector<float> c((size_t)N), hb(bias ? N : 0);
+    CK(hipMemcpy(h.data(), ref, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (bias) CK(hipMemcpy(hb.data(), bias, N * sizeof(float), hipMemcpyDeviceToHost));
+    double worst = 0.0, scale = 1e-30;
+    for (size_t i = 0; i < h.size(); ++i) scale = fmax(scale, fabs(h[i]));
+    for (int r = 0; r < rows; ++r) {
+        CK(hipMemcpy(c.data(), C + (long)r * row_step * ldc, N * sizeof(float), hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            const double want = h[(size_t)r * N + n] + (bias ? hb[n] : 0.0);
+            worst = fmax(worst, fabs(c[n] - want) / scale);
+        }
+    }
+    CK(hipFree(ref));
+    return worst;
+}
+
+extern "C" void vb_debug_gemm_cycles(unsigned long long* dev_buf);
+static unsigned long long* g_cyc = nullptr;
+// cycles per K step of one block (block 128) in the last launch, and the implied shader clock given the wall time
+static void report_cycles(double us) {
+    unsigned long long h[2];
+    CK(hipMemcpy(h, g_cyc, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[1] > 0) printf("        block 128: %llu cycles / %llu K steps = %.0f cycles per step; loop span %.1f%% of the launch at 2.4 GHz\n",
+                         h[0], h[1], (double)h[0] / h[1], 100.0 * h[0] / 2400.0 / us);
+}
+
+struct Shape { int M, N, K, nseg; };
+
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const bool do_check = !(argc > 1 && !strcmp(argv[1], "nocheck"));
+    const int Mr = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 9216;
+    std::vector<Shape> shapes = {{Mr, 768, 768, 1}, {Mr, 768, 768, 3}, {Mr, 3072, 768, 1}, {Mr, 768, 3072, 1},
+                                 {Mr, 1024, 1024, 1}, {Mr, 1024, 1024, 3}, {Mr, 1024, 768, 3}, {Mr, 1024, 2048, 1}};
+    if (quick) shapes = {{Mr, 768, 768, 1}, {Mr, 3072, 768, 1}, {Mr, 1024, 1024, 3}};
+    printf("VB_GEMM_V2=%s VB_GEMM_TILE=%s VB_GEMM_ABL=%s M=%d\n", getenv("VB_GEMM_V2") ? getenv("VB_GEMM_V2") : "-",
+           getenv("VB_GEMM_TILE") ? getenv("VB_GEMM_TILE") : "-", getenv("VB_GEMM_ABL") ? getenv("VB_GEMM_ABL") : "-", Mr);
+    CK(hipMalloc(&g_cyc, 16));
+    CK(hipMemset(g_cyc, 0, 16));
+    if (getenv("LAB_CYCLES")) vb_debug_gemm_cycles(g_cyc);
+    double tot_f = 0, tot_t = 0;
+    for (const Shape& s : shapes) {
+        const int M = s.M, n = s.N, K = s.K, nseg = s.nseg, N = n * nseg;
+        float* x = dev_rand((long)M * K, 1, 1.0f);
+        float* w = dev_rand((long)N * K, 2, 0.05f);     // the nseg weight blocks, contiguous here
+        float* b = dev_rand(N, 3, 1.0f);
+        float* y = dev_rand((long)M * N, 4, 0.0f);
+        float* dy = dev_rand((long)M * N, 5, 1.0f);
+        float* dx = dev_rand((long)M * K, 6, 0.0f);
+        float* dw = dev_rand((long)N * K, 7, 0.0f);
+        float* db = dev_rand(N, 8, 0.0f);
+        const double fl = 2.0 * M * N * K;
+        const int iters = 20;
+        // forward
+        vb_linear_args a;
+        memset(&a, 0, sizeof(a));
+        a.M = M; a.K = K; a.nseg = nseg; a.seg_n = n; a.A = x; a.lda = K; a.ldw = K; a.C = y; a.ldc = N;
+        for (int i = 0; i < nseg; ++i) { a.W[i] = w + (long)i * n * K; a.bias[i] = b + (long)i * n; }
+        double us = time_us([&] { int e = vb_linear_fwd(nullptr, &a); if (e) { fprintf(stderr, "fwd err %d\n", e); exit(1); } }, iters);
+        double err = do_check ? check(M, N, K, x, K, 1, w, K, 1, y, N, b) : -1;
+        printf("fwd   M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
+        if (getenv("LAB_CYCLES")) report_cycles(us);
+        tot_f += fl; tot_t += us;
+        // dgrad: dx[M,K] = dy[M,N] . W[N,K]
+        vb_linear_bwd_input_args g;
+        memset(&g, 0, sizeof(g));
+        g.M = M; g.K = K; g.nseg = nseg; g.seg_n = n; g.dY = dy; g.ldy = N; g.ldw = K; g.dX = dx; g.ldx = K;
+        for (int i = 0; i < nseg; ++i) g.W[i] = w + (long)i * n * K;
+        us = time_us([&] { int e = vb_linear_bwd_input(nullptr, &g); if (e) { fprintf(stderr, "dgrad err %d\n", e); exit(1); } }, iters);
+        err = do_check ? check(M, K, N, dy, N, 1, w, 1, K, dx, K, nullptr) : -1;
+        printf("dgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
+        if (getenv("LAB_CYCLES")) report_cycles(us);
+        tot_f += fl; tot_t += us;
+        // wgrad: dw[N,K] = dy^T . x (+ bias gradient)
+        vb_linear_bwd_weight_args wg;
+        memset(&wg, 0, sizeof(wg));
+        wg.M = M; wg.K = K; wg.nseg = nseg; wg.seg_n = n; wg.dY = dy; wg.ldy = N; wg.X = x; wg.ldx = K; wg.ldw = K;
+        for (int i = 0; i < nseg; ++i) { wg.dW[i] = dw + (long)i * n * K; wg.dbias[i] = db + (long)i * n; }
+        us = time_us([&] { int e = vb_linear_bwd_weight(nullptr, &wg); if (e) { fprintf(stderr, "wgrad err %d\n", e); exit(1); } }, iters);
+        err = do_check ? check(N, K, M, dy, 1, N, x, 1, K, dw, K, nullptr) : -1;
+        printf("wgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
+        tot_f += fl; tot_t += us;
+        for (float* p : {x, w, b, y, dy, dx, dw, db}) CK(hipFree(p));
+    }
+    printf("aggregate: %.1f TF\n", tot_f / tot_t / 1e6);
+    return 0;
+}

@@ -33,7 +33,7 @@
 // of logical tiles (N fastest) and the blocks sharing an A panel share one L2.
 #include <string.h>
 
-#include "gemm_core.h"
+#include "gemm_v2.h"
 
 namespace {
 
@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
     }
 }
 
+unsigned long long* g_dbg = nullptr;   // lab only: where block 128 of the next v2 launches stores its cycle span
+
 // GEMM arithmetic mode: 0 = exact fp32 MFMA, 3 = bf16x6, 2 = bf16x3 (number of bf16 operand planes).
 int g_gemm_mode = -1;
 
@@ -263,14 +265,92 @@ int gemm_mode() {
     return g_gemm_mode;
 }
 
+// ---- second-generation kernel (gemm_v2.h): eligibility + tile / split plan --------------------------------------
+// Cost model: a CU retires "16 x 16 tile K-steps" at a fixed rate once its matrix pipes are saturated, the blocks of
+// a launch are dealt round-robin, so the launch takes ceil(blocks / 256) blocks of TM TN (K steps + overhead) tile
+// steps on the busiest CU; eff = measured relative main-loop efficiency of the tile shape (tools/gemm_lab).
+struct V2Plan { int tm, tn, tiles_m, tiles_n, splits, kt_per_split; };
+
+bool aligned_ld(const void* ptr, long ld) { return ptr == nullptr || (vb_aligned16(ptr) && ld % 4 == 0); }
+
 template <bool A_KC, bool B_KC>
-int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
+bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
+    static const int enabled = [] { const char* e = getenv("VB_GEMM_V2"); return e ? atoi(e) : 1; }();
+    static const int forced_tm = [] { const char* e = getenv("VB_GEMM_TILE"); return e ? atoi(e) / 10 : 0; }();
+    static const int forced_tn = [] { const char* e = getenv("VB_GEMM_TILE"); return e ? atoi(e) % 10 : 0; }();
+    if (!enabled || !vec || p.K % V2_BK != 0 || p.N % 4 != 0) return false;
+    if (!A_KC && p.M % 4 != 0) return false;
+    if (!B_KC && p.bseg % V2_BK != 0) return false;   // a K tile must not straddle two stacked weight segments
+    for (int s = 0; s < VB_MAX_SEGMENTS; ++s)
+        if (!aligned_ld(p.C[s], p.ldc) || !aligned_ld(p.bias[s], 4)) return false;
+    if (!aligned_ld(p.R, p.ldr) || !aligned_ld(p.D, p.ldd) || !aligned_ld(p.mul, p.ldmul)) return false;
+    if (B_KC && p.bseg % 4 != 0) return false;
+    constexpr bool FWD = A_KC && B_KC, DGRAD = A_KC && !B_KC;
+    const int e = p.epi;
+    const bool epi_ok = e == EPI_STORE || (FWD && (e == EPI_GELU || e == EPI_DGELU || e == EPI_RES_DROP)) ||
+                        ((FWD || DGRAD) && e == EPI_RES) || (DGRAD && e == EPI_MUL) || (!FWD && e == EPI_ACCUM) ||
+                        (!FWD && !DGRAD && (e == EPI_ATOMIC || splits != 1));
+    if (!epi_ok) return false;
+    static const int menu[5][2] = {{4, 4}, {3, 4}, {4, 3}, {3, 3}, {2, 2}};
+    static const double eff[5] = {1.0, 0.98, 0.98, 0.93, 0.80};   // tools/gemm_lab, round 2
+    const int kt_total = p.K / V2_BK;
+    const bool multi_seg = p.C[1] != nullptr;
+    double best_cost = 1e300;
+    for (int c = 0; c < 5; ++c) {
+        const int tm = menu[c][0], tn = menu[c][1];
+        if (forced_tm && (tm != forced_tm || tn != forced_tn)) continue;
+        if (multi_seg && p.cseg % (32 * tm) != 0) continue;   // tiles must not straddle two C row segments
+        const int tiles_m = (p.M + 32 * tm - 1) / (32 * tm), tiles_n = (p.N + 32 * tn - 1) / (32 * tn);
+        const long tiles = (long)tiles_m * tiles_n;
+        // split candidates: 1 (given) or, for the split-K launches (splits < 0 = choose), whatever fills the chip
+        const int smax = splits < 0 ? (kt_total / 4 > 0 ? (kt_total / 4 < 96 ? kt_total / 4 : 96) : 1) : 1;
+        for (int sp = 1; sp <= smax; ++sp) {
+            const int per = (kt_total + sp - 1) / sp;
+            const int real = (kt_total + per - 1) / per;
+            if (real != sp) continue;
+            const long blocks = tiles * sp;
+            const double ovh = sp > 1 ? 3.5 : 2.0;
+            // a CU with a single resident block (one wave per SIMD) leaves its matrix pipes idle through every
+            // barrier / prologue / epilogue; from 3 co-resident blocks on they are covered
+            const long per_cu = (blocks + 255) / 256;
+            const int occ_cap = tm * tn <= 9 ? 4 : 3;
+            const long co = per_cu < occ_cap ? per_cu : occ_cap;
+            static const double occ_eff[5] = {0.0, 0.70, 0.90, 0.97, 1.0};
+            const double cost = (double)per_cu * tm * tn * (per + ovh) / (eff[c] * occ_eff[co]);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = {tm, tn, tiles_m, tiles_n, sp, per}; }
+        }
+    }
+    return best_cost < 1e299;
+}
+
+// splits: 1 = no split-K; < 0 = split-K launch (wgrad), choose the count; legacy_splits = count for the round-1 kernel
+template <bool A_KC, bool B_KC>
+int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits = 1) {
     static const int flags = [] { const char* e = getenv("VB_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
     p.flags = flags;
-    plan_tiles(p, splits, gemm_mode() != 0);
     // VB_GEMM_MODE: "f32" (default) = exact fp32 MFMA; "bf16x6" / "bf16x3" = fp32 emulated on the bf16
-    // matrix cores with 3 / 2 operand planes (gemm_split.hip)
+    // matrix cores with 3 / 2 operand planes (gemm_planes.hip)
     const int planes = gemm_mode();
+    V2Plan pl;
+    p.dbg = g_dbg;
+    if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec, splits, pl)) {
+        p.tiles_n = pl.tiles_n;
+        p.ktiles_per_split = pl.kt_per_split;
+        if (splits < 0) p.epi = pl.splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
+        const int tiles = pl.tiles_m * pl.tiles_n;
+        if (A_KC && B_KC) return launch_gemm_v2_nt(st, p, pl.tm, pl.tn, tiles, pl.splits);
+        if (A_KC) return launch_gemm_v2_nn(st, p, pl.tm, pl.tn, tiles, pl.splits);
+        return launch_gemm_v2_tn(st, p, pl.tm, pl.tn, tiles, pl.splits);
+    }
+    // round-1 kernel: any alignment, ragged K, every epilogue
+    if (splits < 0) {
+        splits = legacy_splits;
+        const int kt_total = (p.K + BK - 1) / BK;
+        p.ktiles_per_split = (kt_total + splits - 1) / splits;
+        splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
+        p.epi = splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
+    }
+    plan_tiles(p, splits, planes != 0);
     dim3 grid(p.n_big + p.n_small, splits), block(256);
     if (planes != 0) {
         // operands split into bf16 planes on their way into LDS (gemm_planes.hip)
@@ -285,6 +365,10 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits) {
 }
 
 }  // namespace
+
+// Laboratory hook (tools/gemm_lab.cpp, not part of the product ABI): device buffer of 2 x uint64 receiving
+// {shader cycles of the K loop of block 128, its K steps} of every following second-generation GEMM launch.
+extern "C" void vb_debug_gemm_cycles(unsigned long long* dev_buf) { g_dbg = dev_buf; }
 
 extern "C" int vb_set_gemm_mode(int planes) {
     const int prev = gemm_mode();
@@ -311,6 +395,7 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     p.C[0] = a->C; p.ldc = a->ldc; p.cseg = (p.M + 127) / 128 * 128;
     p.R = a->residual; p.ldr = a->ldr;
     p.P = a->preact; p.ldp = a->ldp;
+    p.D = a->act_grad; p.ldd = a->ldg;
     p.act = a->act; p.accumulate = 0;
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
     if (a->dropout_p > 0.f && a->ldc != p.N) return VB_E_ALIGN;
@@ -320,6 +405,8 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     else if (a->act == VB_ACT_NONE && a->preact == nullptr) p.epi = a->residual != nullptr ? EPI_RES : EPI_STORE;
     else if (a->act == VB_ACT_GELU && a->residual == nullptr) p.epi = a->preact != nullptr ? EPI_PRE_GELU : EPI_GELU;
     else p.epi = EPI_GENERIC;
+    if (a->act_grad != nullptr)
+        p.epi = (p.epi == EPI_GELU && a->dropout_p == 0.f) ? EPI_DGELU : EPI_GENERIC;
     p.ktiles_per_split = (p.K + BK - 1) / BK;
     return launch_gemm<true, true>(static_cast<hipStream_t>(stream), p, vec, 1);
 }
@@ -355,6 +442,11 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
         p.R = a->residual; p.ldr = a->ldr;
         if (p.R != nullptr) p.epi = p.accumulate ? EPI_GENERIC : EPI_RES;
         else p.epi = p.accumulate ? EPI_ACCUM : EPI_STORE;
+        if (a->mul != nullptr) {
+            if (!fused) return VB_E_SEGMENT;
+            p.mul = a->mul; p.ldmul = a->ldm;
+            p.epi = (p.R == nullptr && !p.accumulate) ? EPI_MUL : EPI_GENERIC;
+        }
         p.ktiles_per_split = (p.K + BK - 1) / BK;
         if (int e = launch_gemm<true, false>(st, p, vec, 1)) return e;
     }
@@ -418,12 +510,10 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
                 if (fill >= 0.93) break;
             }
         }
-        p.ktiles_per_split = (kt_total + splits - 1) / splits;
-        splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
         const bool vec = (a->seg_n % 4 == 0) && (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) &&
                          vb_aligned16(p.A) && vb_aligned16(a->X);
-        p.epi = splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
-        if (int e = launch_gemm<false, false>(st, p, vec, splits)) return e;
+        p.epi = EPI_ATOMIC;
+        if (int e = launch_gemm<false, false>(st, p, vec, -1, splits)) return e;
     }
     return 0;
 }

@@ -30,6 +30,7 @@ class LinearArgs(ctypes.Structure):
         ("C", _c_f32p), ("ldc", ctypes.c_int64),
         ("residual", _c_f32p), ("ldr", ctypes.c_int64),
         ("preact", _c_f32p), ("ldp", ctypes.c_int64),
+        ("act_grad", _c_f32p), ("ldg", ctypes.c_int64),
         ("act", ctypes.c_int32),
         ("dropout_p", ctypes.c_float),
         ("seed", ctypes.c_uint64),
@@ -76,6 +77,7 @@ class LinearBwdInputArgs(ctypes.Structure):
         ("dX", _c_f32p), ("ldx", ctypes.c_int64),
         ("accumulate", ctypes.c_int32),
         ("residual", _c_f32p), ("ldr", ctypes.c_int64),
+        ("mul", _c_f32p), ("ldm", ctypes.c_int64),
     ]
 
 
