@@ -57,6 +57,16 @@ const char* vb_error_string(int code);
  * bf16x3). */
 int vb_set_gemm_mode(int planes);
 
+/* Tile selection of the fp32 GEMM kernels. Aligned launches (16-byte pointers, K % 16 == 0, N % 4 == 0) run the
+ * second-generation kernel (v_mfma_f32_16x16x4_f32, block tile 32 TM x 32 TN from the menu 64x64, 96x96, 96x128,
+ * 128x96, 128x128, chosen by a cost model so that the tile count fills whole rounds of the 256 CUs); everything else
+ * runs the round-1 kernel (v_mfma_f32_32x32x2_f32, 128x128 + 64x64 tail tiles, any alignment / ragged K).
+ * One launch may mix two tile heights (e.g. M = 9472 rows = 8 x 128 + 88 x 96: exactly 3 blocks per CU).
+ * code: 0 = cost model (default), 10 TM + TN in {22, 33, 34, 43, 44} = force that tile, 100 TM1 + 10 TM2 + TN in
+ * {434, 433, 324, 323} = force that mixed-height pair, -1 = round-1 kernel only.
+ * Returns the previous code; an unknown value only queries. Environment: VB_GEMM_TILE=<code>, VB_GEMM_V2=0. */
+int vb_set_gemm_tile(int code);
+
 /* ------------------------------------------------------------------------------------------
  * vb_linear_fwd:  C[M, nseg*seg_n] = act( A[M,K] . W^T + bias ) (+ residual)
  *

@@ -33,7 +33,7 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
+EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd"]
 
 
@@ -118,4 +118,8 @@ def test_gemm_kernels_keep_their_register_budget(native):
                 assert int(scratch) == 0, "%s spills %s bytes/lane" % (fn, scratch)
             if "gemm_f32_kernel" in fn:
                 assert int(vgprs) <= 128, "%s uses %s VGPRs" % (fn, vgprs)
+            m = re.search(r"gemm_v2_kernelILi(\d)ELi(\d)E", fn)
+            if m:   # second-generation kernels: 4 blocks per CU up to 96 x 96 tiles, 3 above
+                budget = 128 if int(m.group(1)) * int(m.group(2)) <= 9 else 168
+                assert int(vgprs) <= budget, "%s uses %s VGPRs (budget %d)" % (fn, vgprs, budget)
     assert seen > 20

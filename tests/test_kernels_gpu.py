@@ -47,6 +47,61 @@ def test_linear_plain(ops, M, N, K):
     _close(y, x.double() @ w.double().t() + b.double())
 
 
+@pytest.fixture
+def gemm_tile():
+    """Forces a tile of the second-generation GEMM kernel (or the round-1 kernel) for one test."""
+    from vilbert import _native
+    prev = _native.set_gemm_tile(0)
+
+    def use(code):
+        _native.set_gemm_tile(code)
+    yield use
+    _native.set_gemm_tile(prev)
+
+
+@pytest.mark.parametrize("code", [-1, 0, 22, 33, 34, 43, 44, 434, 433, 324, 323])
+@pytest.mark.parametrize("M,N,K,nseg", [(384, 384, 64, 1), (36 * 11, 768, 16, 1), (300, 260, 48, 1), (96, 96, 16 * 7, 3),
+                                        (1000, 128, 256, 3), (50, 20, 32, 1), (37 * 32, 256, 64, 1)])
+def test_linear_forward_dgrad_wgrad_every_tile(ops, gemm_tile, code, M, N, K, nseg):
+    """Every tile shape of the second-generation kernel (forced) and the round-1 kernel on aligned shapes with full,
+    ragged-M, ragged-N tiles, 1..7 K steps (prologue / steady state / tail of the K loop) and stacked segments:
+    forward, dgrad and wgrad (+ fused bias gradient) against fp64."""
+    gemm_tile(code)
+    x = _rand(M, K, seed=1)
+    ws = [_rand(N, K, seed=10 + i, scale=0.1) for i in range(nseg)]
+    bs = [_rand(N, seed=20 + i) for i in range(nseg)]
+    dy = _rand(M, nseg * N, seed=3)
+    xd, wd = x.cuda(), [w.cuda() for w in ws]
+    y, _ = ops.linear_fwd(xd, wd, [b.cuda() for b in bs])
+    _close(y, torch.cat([x.double() @ w.double().t() + b.double() for w, b in zip(ws, bs)], 1), 3e-5, 3e-5)
+    dx = ops.linear_bwd_input(dy.cuda(), wd, K)
+    _close(dx, dy.double() @ torch.cat(ws, 0).double(), 3e-5, 3e-5 * max(1.0, N * nseg / 256))
+    dws, dbs = ops.linear_bwd_weight(dy.cuda(), xd, nseg, N, [True] * nseg)
+    for s in range(nseg):
+        seg = dy[:, s * N:(s + 1) * N].double()
+        want = seg.t() @ x.double()
+        _close(dws[s], want, 3e-5, 3e-5 * max(1.0, want.abs().max().item()))
+        _close(dbs[s], seg.sum(0), 3e-5, 3e-5 * max(1.0, M / 64))
+
+
+@pytest.mark.parametrize("code", [-1, 0, 33, 44])
+@pytest.mark.parametrize("M,N,K", [(192, 384, 64), (100, 200, 52)])   # aligned (fused epilogue) and ragged (post-pass)
+def test_linear_activation_derivative_and_multiplier_epilogues(ops, gemm_tile, code, M, N, K):
+    """act_grad (forward stores gelu'(pre-activation)) and mul (dgrad multiplies its result) - the fused GELU
+    backward of the feed-forward blocks - in the second-generation kernel and through the round-1 kernel's post-passes."""
+    gemm_tile(code)
+    x, w, b = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1), _rand(N, seed=9)
+    y, d = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()], act="gelu", want_act_grad=True)
+    pre = (x.double() @ w.double().t() + b.double()).requires_grad_(True)
+    act = _gelu64(pre)
+    act.sum().backward()
+    _close(y, act.detach())
+    _close(d, pre.grad)
+    dy, m = _rand(M, N, seed=11), _rand(M, K, seed=12)
+    dx = ops.linear_bwd_input(dy.cuda(), [w.cuda()], K, mul=m.cuda())
+    _close(dx, (dy.double() @ w.double()) * m.double(), 3e-5, 3e-5)
+
+
 def test_linear_is_transpose_detecting(ops):
     # asymmetric A = I-like check: y = x @ w.T with x = one-hot rows picks rows of w.T
     K, N = 64, 160

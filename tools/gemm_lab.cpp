@@ -90,7 +90,7 @@ static double check(int M, int N, int K, const float* A, long a_rs, long a_cs, c
     return worst;
 }
 
-extern "C" void vb_debug_gemm_cycles(unsigned long long* dev_buf);
+extern "C" void vblab_gemm_cycles(unsigned long long* dev_buf);
 static unsigned long long* g_cyc = nullptr;
 // cycles per K step of one block (block 128) in the last launch, and the implied shader clock given the wall time
 static void report_cycles(double us) {
@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
            getenv("VB_GEMM_TILE") ? getenv("VB_GEMM_TILE") : "-", getenv("VB_GEMM_ABL") ? getenv("VB_GEMM_ABL") : "-", Mr);
     CK(hipMalloc(&g_cyc, 16));
     CK(hipMemset(g_cyc, 0, 16));
-    if (getenv("LAB_CYCLES")) vb_debug_gemm_cycles(g_cyc);
+    if (getenv("LAB_CYCLES")) vblab_gemm_cycles(g_cyc);
     double tot_f = 0, tot_t = 0;
     for (const Shape& s : shapes) {
         const int M = s.M, n = s.N, K = s.K, nseg = s.nseg, N = n * nseg;

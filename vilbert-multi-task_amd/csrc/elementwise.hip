@@ -74,3 +74,43 @@ extern "C" int vb_dropout(void* stream, int64_t n, const float* x, const float* 
     VB_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- post-passes of the round-1 GEMM kernel (ragged / unaligned launches only; the second-generation kernel fuses
+// both into its epilogue) ------------------------------------------------------------------------------------------
+namespace {
+
+// d[r][c] = act'(d[r][c]) in place: d holds the pre-activation on entry
+__global__ __launch_bounds__(256) void act_grad_inplace_kernel(long rows, int cols, float* __restrict__ d, long ld, int act) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    float* q = d + (i / cols) * ld + (i % cols);
+    const float v = *q;
+    *q = act == VB_ACT_GELU ? gelu_grad(v) : (act == VB_ACT_RELU ? (v > 0.f ? 1.f : 0.f) : 1.f);
+}
+
+__global__ __launch_bounds__(256) void mul_inplace_kernel(long rows, int cols, float* __restrict__ c, long ldc,
+                                                          const float* __restrict__ m, long ldm) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    c[(i / cols) * ldc + (i % cols)] *= m[(i / cols) * ldm + (i % cols)];
+}
+
+}  // namespace
+
+namespace vbgemm {
+
+int launch_act_grad_inplace(hipStream_t st, long rows, int cols, float* d, long ld, int act) {
+    hipLaunchKernelGGL(act_grad_inplace_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, rows, cols,
+                       d, ld, act);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mul_inplace(hipStream_t st, long rows, int cols, float* c, long ldc, const float* m, long ldm) {
+    hipLaunchKernelGGL(mul_inplace_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, st, rows, cols, c,
+                       ldc, m, ldm);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace vbgemm

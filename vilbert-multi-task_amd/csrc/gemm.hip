@@ -265,19 +265,69 @@ int gemm_mode() {
     return g_gemm_mode;
 }
 
+// Tile selection of the second-generation kernel: 0 = cost model, 10 TM + TN = force a menu entry (22 | 33 | 34 | 43 |
+// 44; launches it cannot serve fall back to the round-1 kernel), -1 = round-1 kernel only. Initial value from the
+// environment (VB_GEMM_V2=0 -> -1, VB_GEMM_TILE=<code>).
+int g_gemm_tile = -2;
+
+int gemm_tile_code() {
+    if (g_gemm_tile == -2) {
+        const char* v2 = getenv("VB_GEMM_V2");
+        const char* t = getenv("VB_GEMM_TILE");
+        g_gemm_tile = (v2 != nullptr && atoi(v2) == 0) ? -1 : (t != nullptr ? atoi(t) : 0);
+    }
+    return g_gemm_tile;
+}
+
 // ---- second-generation kernel (gemm_v2.h): eligibility + tile / split plan --------------------------------------
 // Cost model: a CU retires "16 x 16 tile K-steps" at a fixed rate once its matrix pipes are saturated, the blocks of
 // a launch are dealt round-robin, so the launch takes ceil(blocks / 256) blocks of TM TN (K steps + overhead) tile
 // steps on the busiest CU; eff = measured relative main-loop efficiency of the tile shape (tools/gemm_lab).
-struct V2Plan { int tm, tn, tiles_m, tiles_n, splits, kt_per_split; };
+struct V2Plan { int tm1, tm2, tn, big_rows, small_rows, tiles_n, splits, kt_per_split; };
 
 bool aligned_ld(const void* ptr, long ld) { return ptr == nullptr || (vb_aligned16(ptr) && ld % 4 == 0); }
 
+// Modelled duration (arbitrary unit: one 16 x 16 tile K step on a saturated CU) of a launch of n1 tiles of area a1 (in
+// 16 x 16 units) followed by n2 tiles of area a2, every block running `steps` K steps, `occ` blocks resident per CU.
+// Blocks are dealt to the 256 CUs round-robin; a CU's matrix pipes are shared by its resident blocks and lose
+// efficiency when fewer than 3 blocks cover each other's barriers / prologues / epilogues (occ_eff, measured).
+double v2_launch_cost(long n1, int a1, long n2, int a2, double steps, int occ) {
+    static const double occ_eff[5] = {1.0, 0.70, 0.90, 0.97, 1.0};
+    double worst = 0.0;
+    const long q1 = n1 / 256, r1 = n1 % 256, q2 = n2 / 256, r2 = n2 % 256;
+    // the CU classes of a round-robin deal: (extra big tile?, extra small tile?)
+    for (int cls = 0; cls < 4; ++cls) {
+        const bool x1 = cls & 1, x2 = cls & 2;
+        // CUs [0, r1) hold an extra big tile; the small tiles continue the deal at CU r1: CUs [r1, r1 + r2) mod 256
+        long cnt;   // number of CUs in this class
+        const long lo2 = r1, hi2 = r1 + r2;   // extra-small range, may wrap
+        auto in2 = [&](long c) { return hi2 <= 256 ? (c >= lo2 && c < hi2) : (c >= lo2 || c < hi2 - 256); };
+        cnt = 0;
+        // count analytically would be fiddly; 256 iterations only when the class is otherwise plausible
+        for (long c = 0; c < 256; ++c) cnt += ((c < r1) == x1) && (in2(c) == x2);
+        if (cnt == 0) continue;
+        const long b1 = q1 + (x1 ? 1 : 0), b2 = q2 + (x2 ? 1 : 0);
+        long left1 = b1, left2 = b2;
+        double t = 0.0;
+        while (left1 + left2 > 0) {   // resident batches of up to occ blocks (big tiles first)
+            const long take = left1 + left2 < occ ? left1 + left2 : occ;
+            const long t1 = left1 < take ? left1 : take, t2 = take - t1;
+            t += (double)(t1 * a1 + t2 * a2) * steps / occ_eff[take];
+            left1 -= t1;
+            left2 -= t2;
+        }
+        if (t > worst) worst = t;
+    }
+    return worst;
+}
+
 template <bool A_KC, bool B_KC>
 bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
-    static const int enabled = [] { const char* e = getenv("VB_GEMM_V2"); return e ? atoi(e) : 1; }();
-    static const int forced_tm = [] { const char* e = getenv("VB_GEMM_TILE"); return e ? atoi(e) / 10 : 0; }();
-    static const int forced_tn = [] { const char* e = getenv("VB_GEMM_TILE"); return e ? atoi(e) % 10 : 0; }();
+    const int code = gemm_tile_code();
+    const bool enabled = code >= 0;
+    // forced tile: 10 TM + TN (single height) or 100 TM1 + 10 TM2 + TN (mixed heights)
+    const int forced_tm1 = code >= 100 ? code / 100 : code / 10, forced_tm2 = code >= 100 ? (code / 10) % 10 : code / 10;
+    const int forced_tn = code % 10;
     if (!enabled || !vec || p.K % V2_BK != 0 || p.N % 4 != 0) return false;
     if (!A_KC && p.M % 4 != 0) return false;
     if (!B_KC && p.bseg % V2_BK != 0) return false;   // a K tile must not straddle two stacked weight segments
@@ -288,39 +338,56 @@ bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
     constexpr bool FWD = A_KC && B_KC, DGRAD = A_KC && !B_KC;
     const int e = p.epi;
     const bool epi_ok = e == EPI_STORE || (FWD && (e == EPI_GELU || e == EPI_DGELU || e == EPI_RES_DROP)) ||
-                        ((FWD || DGRAD) && e == EPI_RES) || (DGRAD && e == EPI_MUL) || (!FWD && e == EPI_ACCUM) ||
-                        (!FWD && !DGRAD && (e == EPI_ATOMIC || splits != 1));
+                        ((FWD || DGRAD) && e == EPI_RES) || (DGRAD && (e == EPI_MUL || e == EPI_ACCUM)) ||
+                        (!A_KC && (e == EPI_ATOMIC || e == EPI_ACCUM || splits != 1));
     if (!epi_ok) return false;
-    static const int menu[5][2] = {{4, 4}, {3, 4}, {4, 3}, {3, 3}, {2, 2}};
-    static const double eff[5] = {1.0, 0.98, 0.98, 0.93, 0.80};   // tools/gemm_lab, round 2
-    const int kt_total = p.K / V2_BK;
     const bool multi_seg = p.C[1] != nullptr;
+    // plans are cached per problem shape (a training step launches the same ~30 shapes thousands of times)
+    struct Key { int layout, M, N, K, cseg, splits, code; };
+    struct Entry { Key k; bool ok; V2Plan pl; };
+    static thread_local Entry cache[64];
+    static thread_local int cache_n = 0;
+    const Key key{(A_KC ? 2 : 0) + (B_KC ? 1 : 0), p.M, p.N, p.K, multi_seg ? p.cseg : 0, splits, code};
+    for (int i = 0; i < cache_n; ++i)
+        if (!memcmp(&cache[i].k, &key, sizeof(Key))) { best = cache[i].pl; return cache[i].ok; }
+
+    // {tm1, tm2, tn}: single-height tiles and the mixed-height pairs compiled in gemm_v2.hip
+    static const int menu[9][3] = {{4, 4, 4}, {3, 3, 4}, {4, 4, 3}, {3, 3, 3}, {2, 2, 2}, {4, 3, 4}, {4, 3, 3}, {3, 2, 4}, {3, 2, 3}};
+    // relative main-loop efficiency of a tile shape (tools/gemm_lab, round 2): bigger tiles move fewer bytes per FLOP
+    auto eff = [](int tm, int tn) { return tm * tn >= 16 ? 1.0 : tm * tn >= 12 ? 0.98 : tm * tn >= 9 ? 0.93 : 0.80; };
+    const int kt_total = p.K / V2_BK;
     double best_cost = 1e300;
-    for (int c = 0; c < 5; ++c) {
-        const int tm = menu[c][0], tn = menu[c][1];
-        if (forced_tm && (tm != forced_tm || tn != forced_tn)) continue;
-        if (multi_seg && p.cseg % (32 * tm) != 0) continue;   // tiles must not straddle two C row segments
-        const int tiles_m = (p.M + 32 * tm - 1) / (32 * tm), tiles_n = (p.N + 32 * tn - 1) / (32 * tn);
-        const long tiles = (long)tiles_m * tiles_n;
-        // split candidates: 1 (given) or, for the split-K launches (splits < 0 = choose), whatever fills the chip
-        const int smax = splits < 0 ? (kt_total / 4 > 0 ? (kt_total / 4 < 96 ? kt_total / 4 : 96) : 1) : 1;
-        for (int sp = 1; sp <= smax; ++sp) {
-            const int per = (kt_total + sp - 1) / sp;
-            const int real = (kt_total + per - 1) / per;
-            if (real != sp) continue;
-            const long blocks = tiles * sp;
-            const double ovh = sp > 1 ? 3.5 : 2.0;
-            // a CU with a single resident block (one wave per SIMD) leaves its matrix pipes idle through every
-            // barrier / prologue / epilogue; from 3 co-resident blocks on they are covered
-            const long per_cu = (blocks + 255) / 256;
-            const int occ_cap = tm * tn <= 9 ? 4 : 3;
-            const long co = per_cu < occ_cap ? per_cu : occ_cap;
-            static const double occ_eff[5] = {0.0, 0.70, 0.90, 0.97, 1.0};
-            const double cost = (double)per_cu * tm * tn * (per + ovh) / (eff[c] * occ_eff[co]);
-            if (cost < best_cost - 1e-9) { best_cost = cost; best = {tm, tn, tiles_m, tiles_n, sp, per}; }
+    for (int c = 0; c < 9; ++c) {
+        const int tm1 = menu[c][0], tm2 = menu[c][1], tn = menu[c][2];
+        if (code > 0 && (tm1 != forced_tm1 || tm2 != forced_tm2 || tn != forced_tn)) continue;
+        if (tm1 != tm2 && splits != 1) continue;   // mixed heights: forward / dgrad only (wgrad tiles a weight matrix)
+        if (multi_seg && (tm1 != tm2 || p.cseg % (32 * tm1) != 0)) continue;   // tiles must not straddle two C row segments
+        const int bm1 = 32 * tm1, bm2 = 32 * tm2;
+        const int tiles_n = (p.N + 32 * tn - 1) / (32 * tn);
+        const int occ = (tm1 * tn <= 9 && FWD) ? 4 : 3;
+        const int max_big = tm1 == tm2 ? 0 : p.M / bm1;
+        for (int nb = 0; nb <= max_big; ++nb) {
+            // nb row tiles of the taller kind (mixed launches only), the rest of the rows in bm2-row tiles
+            const int rest = p.M - nb * bm1;
+            const int ns = tm1 == tm2 ? (p.M + bm2 - 1) / bm2 : (rest + bm2 - 1) / bm2;
+            if (tm1 != tm2 && (nb == 0 || ns == 0)) continue;
+            const long n1 = (long)nb * tiles_n, n2 = (long)ns * tiles_n;
+            const int smax = splits < 0 ? (kt_total / 4 > 0 ? (kt_total / 4 < 96 ? kt_total / 4 : 96) : 1) : 1;
+            for (int sp = 1; sp <= smax; ++sp) {
+                const int per = (kt_total + sp - 1) / sp;
+                if ((kt_total + per - 1) / per != sp) continue;
+                const double steps = per + (sp > 1 ? 3.5 : 2.0);
+                const double cost = v2_launch_cost(n1 * sp, tm1 * tn, n2 * sp, tm2 * tn, steps, occ) / eff(tm2, tn);
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
+                    best = {tm1, tm2, tn, nb, ns, tiles_n, sp, per};
+                }
+            }
         }
     }
-    return best_cost < 1e299;
+    const bool ok = best_cost < 1e299;
+    if (cache_n < 64) cache[cache_n++] = Entry{key, ok, best};
+    return ok;
 }
 
 // splits: 1 = no split-K; < 0 = split-K launch (wgrad), choose the count; legacy_splits = count for the round-1 kernel
@@ -336,13 +403,29 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec, splits, pl)) {
         p.tiles_n = pl.tiles_n;
         p.ktiles_per_split = pl.kt_per_split;
+        p.n_big = pl.big_rows * pl.tiles_n;
+        p.m_split = pl.big_rows * 32 * pl.tm1;
         if (splits < 0) p.epi = pl.splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
-        const int tiles = pl.tiles_m * pl.tiles_n;
-        if (A_KC && B_KC) return launch_gemm_v2_nt(st, p, pl.tm, pl.tn, tiles, pl.splits);
-        if (A_KC) return launch_gemm_v2_nn(st, p, pl.tm, pl.tn, tiles, pl.splits);
-        return launch_gemm_v2_tn(st, p, pl.tm, pl.tn, tiles, pl.splits);
+        const int tiles = (pl.big_rows + pl.small_rows) * pl.tiles_n;
+        if (A_KC && B_KC) return launch_gemm_v2_nt(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
+        if (A_KC) return launch_gemm_v2_nn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
+        return launch_gemm_v2_tn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
     }
-    // round-1 kernel: any alignment, ragged K, every epilogue
+    // round-1 kernel: any alignment, ragged K, every epilogue. It stores the pre-activation where the activation
+    // derivative is wanted and leaves the multiplier to a post-pass (both fused only in the kernel above; keeping
+    // erf + exp out of this kernel's generic epilogue keeps it free of register spills).
+    float* const want_d = p.D;
+    const float* const want_mul = p.mul;
+    if (want_d != nullptr) {
+        if (p.P != nullptr) return VB_E_BADARG;
+        p.P = p.D; p.ldp = p.ldd; p.D = nullptr;
+        if (p.epi == EPI_DGELU) p.epi = EPI_PRE_GELU;
+    }
+    if (want_mul != nullptr) {
+        if (p.accumulate || splits != 1) return VB_E_BADARG;
+        p.mul = nullptr;
+        if (p.epi == EPI_MUL) p.epi = EPI_STORE;
+    }
     if (splits < 0) {
         splits = legacy_splits;
         const int kt_total = (p.K + BK - 1) / BK;
@@ -354,13 +437,18 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     dim3 grid(p.n_big + p.n_small, splits), block(256);
     if (planes != 0) {
         // operands split into bf16 planes on their way into LDS (gemm_planes.hip)
-        return planes == 3 ? launch_gemm_planes3(st, p, vec, splits, A_KC, B_KC)
-                           : launch_gemm_planes2(st, p, vec, splits, A_KC, B_KC);
+        if (int e = planes == 3 ? launch_gemm_planes3(st, p, vec, splits, A_KC, B_KC)
+                                : launch_gemm_planes2(st, p, vec, splits, A_KC, B_KC))
+            return e;
     } else {
         if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, GEMM_LDS_BYTES, st, p);
         else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, GEMM_LDS_BYTES, st, p);
     }
     VB_LAUNCH_CHECK();
+    if (want_d != nullptr)
+        if (int e = launch_act_grad_inplace(st, p.M, p.N, want_d, p.ldp, p.act)) return e;
+    if (want_mul != nullptr)
+        if (int e = launch_mul_inplace(st, p.M, p.N, p.C[0], p.ldc, want_mul, p.ldmul)) return e;
     return 0;
 }
 
@@ -368,7 +456,15 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
 
 // Laboratory hook (tools/gemm_lab.cpp, not part of the product ABI): device buffer of 2 x uint64 receiving
 // {shader cycles of the K loop of block 128, its K steps} of every following second-generation GEMM launch.
-extern "C" void vb_debug_gemm_cycles(unsigned long long* dev_buf) { g_dbg = dev_buf; }
+extern "C" void vblab_gemm_cycles(unsigned long long* dev_buf) { g_dbg = dev_buf; }
+
+extern "C" int vb_set_gemm_tile(int code) {
+    const int prev = gemm_tile_code();
+    if (code == -1 || code == 0 || code == 22 || code == 33 || code == 34 || code == 43 || code == 44 || code == 434 ||
+        code == 433 || code == 324 || code == 323)
+        g_gemm_tile = code;
+    return prev;
+}
 
 extern "C" int vb_set_gemm_mode(int planes) {
     const int prev = gemm_mode();

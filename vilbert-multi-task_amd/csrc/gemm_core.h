@@ -32,12 +32,13 @@ struct GemmP {
     int accumulate;       // C += result
     int tiles_n;          // big-tile grid columns
     int n_big, n_small;   // blocks [0, n_big): big tiles; [n_big, n_big + n_small): small tiles
+    int m_split;          // second-generation kernel: rows [0, m_split) are cut into the taller tiles
     int ktiles_per_split; // split-K (gridDim.y > 1): atomicAdd into C
     int epi;              // EPI_* fast path of interior tiles
     int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
     float drop_p, drop_scale;  // dropout on the activated value, before the residual (0 = off)
     uint64_t seed;
-    unsigned long long* dbg;   // lab only (vb_debug_gemm_cycles): block 0 stores its shader-clock span here
+    unsigned long long* dbg;   // lab only (vblab_gemm_cycles): block 0 stores its shader-clock span here
 };
 
 // XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).
@@ -113,7 +114,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
     }
     const int row0 = m0 + wm * 32 * TM + 4 * hi, col0 = n0 + wn * 32 * TN + l31;
     float* cptr = p.C[cs] + (long)(row0 - cs * p.cseg) * p.ldc + col0;
-    if (m0 + RA <= p.M && n0 + RB <= p.N && p.epi != EPI_GENERIC && p.epi != EPI_DGELU && p.epi != EPI_MUL) {
+    if (m0 + RA <= p.M && n0 + RB <= p.N && p.epi != EPI_GENERIC) {
         switch (p.epi) {
             case EPI_STORE: epilogue_full<EPI_STORE, TM, TN>(p, cptr, acc, bv, row0, col0); break;
             case EPI_GELU: epilogue_full<EPI_GELU, TM, TN>(p, cptr, acc, bv, row0, col0); break;
@@ -139,13 +140,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bv[j];
                 if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
-                if (p.D != nullptr)
-                    p.D[(long)row * p.ldd + col] = p.act == VB_ACT_GELU ? gelu_grad(v) : (p.act == VB_ACT_RELU ? (v > 0.f ? 1.f : 0.f) : 1.f);
                 if (p.act == VB_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
                 if (p.drop_p > 0.f) v = vb_keep(p.seed, (uint64_t)((long)row * p.N + col), p.drop_p) ? v * p.drop_scale : 0.f;
                 if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
-                if (p.mul != nullptr) v *= p.mul[(long)row * p.ldmul + col];
                 float* c = cptr + (long)dr * p.ldc + j * 32;
                 if (split) unsafeAtomicAdd(c, v);
                 else if (p.accumulate) *c += v;
@@ -196,10 +194,15 @@ __device__ __forceinline__ void load_tile_kc(f32x4 (&reg)[NLD], const float* con
 }
 
 
+// post-passes of the round-1 kernel for the two epilogues only the second-generation kernel fuses (elementwise.hip)
+int launch_act_grad_inplace(hipStream_t st, long rows, int cols, float* d, long ld, int act);
+int launch_mul_inplace(hipStream_t st, long rows, int cols, float* c, long ldc, const float* m, long ldm);
+
 // second-generation fp32 kernels (gemm_v2.hip, one object per operand layout): launch tile (32 tm) x (32 tn)
-int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits);
-int launch_gemm_v2_nn(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits);
-int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits);
+// (p.n_big blocks of (32 tm1) x (32 tn) over rows [0, p.m_split), then tiles - p.n_big blocks of (32 tm2) x (32 tn))
+int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits);
+int launch_gemm_v2_nn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits);
+int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits);
 
 // bf16-planes kernels (gemm_planes.hip, one object per plane count): launch for operand layouts (a_kc, b_kc)
 int launch_gemm_planes3(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);

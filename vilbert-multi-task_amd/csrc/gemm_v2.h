@@ -48,7 +48,8 @@ struct V2Cfg {
     static constexpr int DUMP = V2_STAGES * STAGE;
     static constexpr int LDS_BYTES = (V2_STAGES * STAGE + 256 * 4) * 4;
     // co-resident blocks per CU the kernel is compiled for (register budget 512 / OCC per lane)
-    static constexpr int OCC = (TM * TN <= 9) ? 4 : 3;
+    // (a row-contiguous operand tile is padded: 4 blocks of 96 x 96 no longer fit the 160 KiB of LDS)
+    static constexpr int OCC = (TM * TN <= 9 && A_KC && B_KC) ? 4 : 3;
 };
 
 __device__ __forceinline__ int v2_swz(int row) { return (-(row >> 2)) & 3; }

@@ -2,7 +2,8 @@
 //   -DVB_V2_LAYOUT=0  forward  (NT)  A k-contiguous,   B k-contiguous
 //   -DVB_V2_LAYOUT=1  dgrad    (NN)  A k-contiguous,   B row-contiguous
 //   -DVB_V2_LAYOUT=2  wgrad    (TN)  A row-contiguous, B row-contiguous
-// Each object instantiates the tile menu {64x64, 96x96, 96x128, 128x96, 128x128} (block tile = 32 TM x 32 TN).
+// Each object instantiates the tile menu {64x64, 96x96, 96x128, 128x96, 128x128} (block tile = 32 TM x 32 TN) and the
+// mixed-height launches {128 | 96} x {128, 96}, {96 | 64} x {128, 96}.
 #include "gemm_v2.h"
 
 #ifndef VB_V2_LAYOUT
@@ -16,48 +17,69 @@ using namespace vbgemm;
 constexpr bool A_KC = VB_V2_LAYOUT != 2;
 constexpr bool B_KC = VB_V2_LAYOUT == 0;
 
-template <int TM, int TN, int ABL>
-__global__ __launch_bounds__(256, (V2Cfg<TM, TN, A_KC, B_KC>::OCC)) void gemm_v2_kernel(const GemmP p) {
+// One launch may mix two tile heights (same width): blocks [0, n_big) cut rows [0, m_split) into (32 TM1)-row tiles,
+// the rest cuts the remaining rows into (32 TM2)-row tiles. With 37 regions per sample the image stream has M =
+// 9472 = 8 x 128 + 88 x 96 rows: 96 row tiles x 8 column tiles = 768 blocks, exactly 3 per CU, where a single
+// height gives 592 (128) or 792 (96) blocks and a mostly empty last round.
+template <int TM1, int TM2, int TN, int ABL>
+__global__ __launch_bounds__(256, (V2Cfg<TM1, TN, A_KC, B_KC>::OCC)) void gemm_v2_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware tile order: block b runs on XCD b % 8; each XCD walks a contiguous run of tiles (N fastest), so the
     // blocks that share an A panel share one L2
-    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
-    gemm_tile_v2<TM, TN, A_KC, B_KC, ABL>(p, smem, (t / p.tiles_n) * (32 * TM), (t % p.tiles_n) * (32 * TN));
+    const int b = blockIdx.x;
+    if (TM1 == TM2 || b < p.n_big) {
+        const int t = xcd_swizzle(b, TM1 == TM2 ? (int)gridDim.x : p.n_big);
+        gemm_tile_v2<TM1, TN, A_KC, B_KC, ABL>(p, smem, (t / p.tiles_n) * (32 * TM1), (t % p.tiles_n) * (32 * TN));
+    } else {
+        const int t = xcd_swizzle(b - p.n_big, (int)gridDim.x - p.n_big);
+        gemm_tile_v2<TM2, TN, A_KC, B_KC, ABL>(p, smem, p.m_split + (t / p.tiles_n) * (32 * TM2), (t % p.tiles_n) * (32 * TN));
+    }
 }
 
-template <int TM, int TN>
+template <int TM1, int TM2, int TN>
 int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
-    using Cfg = V2Cfg<TM, TN, A_KC, B_KC>;
-    static const int abl = [] { const char* e = getenv("VB_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    using Cfg = V2Cfg<TM1, TN, A_KC, B_KC>;   // TM1 >= TM2: the taller tile sets the LDS size and the register budget
     dim3 grid(tiles, splits), block(256);
-    if (abl == 1) hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 1>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 2) hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 2>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 3) hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 3>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 4) hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 4>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 5) hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 5>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 6) hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 6>), grid, block, Cfg::LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((gemm_v2_kernel<TM, TN, 0>), grid, block, Cfg::LDS_BYTES, st, p);
+#ifdef VB_GEMM_LAB
+    // ablation variants for tools/gemm_lab (make LAB=1): 1 = no staging, 2 = no barrier, 4 = no global loads,
+    // 5 = loads do not advance, 6 = contiguous load pattern - they time parts of the K loop and give WRONG results
+    static const int abl = [] { const char* e = getenv("VB_GEMM_ABL"); return e ? atoi(e) : 0; }();
+    if (abl == 1) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 1>), grid, block, Cfg::LDS_BYTES, st, p);
+    else if (abl == 2) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 2>), grid, block, Cfg::LDS_BYTES, st, p);
+    else if (abl == 4) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 4>), grid, block, Cfg::LDS_BYTES, st, p);
+    else if (abl == 5) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 5>), grid, block, Cfg::LDS_BYTES, st, p);
+    else if (abl == 6) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 6>), grid, block, Cfg::LDS_BYTES, st, p);
+    else
+#endif
+        hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 0>), grid, block, Cfg::LDS_BYTES, st, p);
     VB_LAUNCH_CHECK();
     return 0;
 }
 
-int dispatch(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits) {
-    if (tm == 2 && tn == 2) return launch<2, 2>(st, p, tiles, splits);
-    if (tm == 3 && tn == 3) return launch<3, 3>(st, p, tiles, splits);
-    if (tm == 3 && tn == 4) return launch<3, 4>(st, p, tiles, splits);
-    if (tm == 4 && tn == 3) return launch<4, 3>(st, p, tiles, splits);
-    if (tm == 4 && tn == 4) return launch<4, 4>(st, p, tiles, splits);
-    return VB_E_RANGE;
+int dispatch(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) {
+    const int code = tm1 * 100 + tm2 * 10 + tn;
+    switch (code) {
+        case 222: return launch<2, 2, 2>(st, p, tiles, splits);
+        case 333: return launch<3, 3, 3>(st, p, tiles, splits);
+        case 334: return launch<3, 3, 4>(st, p, tiles, splits);
+        case 443: return launch<4, 4, 3>(st, p, tiles, splits);
+        case 444: return launch<4, 4, 4>(st, p, tiles, splits);
+        case 434: return launch<4, 3, 4>(st, p, tiles, splits);
+        case 433: return launch<4, 3, 3>(st, p, tiles, splits);
+        case 324: return launch<3, 2, 4>(st, p, tiles, splits);
+        case 323: return launch<3, 2, 3>(st, p, tiles, splits);
+        default: return VB_E_RANGE;
+    }
 }
 
 }  // namespace
 
 namespace vbgemm {
 #if VB_V2_LAYOUT == 0
-int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits) { return dispatch(st, p, tm, tn, tiles, splits); }
+int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) { return dispatch(st, p, tm1, tm2, tn, tiles, splits); }
 #elif VB_V2_LAYOUT == 1
-int launch_gemm_v2_nn(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits) { return dispatch(st, p, tm, tn, tiles, splits); }
+int launch_gemm_v2_nn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) { return dispatch(st, p, tm1, tm2, tn, tiles, splits); }
 #else
-int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm, int tn, int tiles, int splits) { return dispatch(st, p, tm, tn, tiles, splits); }
+int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) { return dispatch(st, p, tm1, tm2, tn, tiles, splits); }
 #endif
 }  // namespace vbgemm

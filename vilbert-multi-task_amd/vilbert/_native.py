@@ -124,6 +124,7 @@ SIGNATURES = {
     "vb_abi_version": (ctypes.c_int, []),
     "vb_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "vb_set_gemm_mode": (ctypes.c_int, [ctypes.c_int]),
+    "vb_set_gemm_tile": (ctypes.c_int, [ctypes.c_int]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
     "vb_linear_bwd_input": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdInputArgs)]),
     "vb_linear_bwd_weight": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdWeightArgs)]),
@@ -166,6 +167,12 @@ def lib():
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib
+
+
+def set_gemm_tile(code):
+    """Tile selection of the fp32 GEMM: 0 = cost model, 22 | 33 | 34 | 43 | 44 = force a tile of the
+    second-generation kernel, -1 = round-1 kernel only. Returns the previous code."""
+    return lib().vb_set_gemm_tile(int(code))
 
 
 GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2}

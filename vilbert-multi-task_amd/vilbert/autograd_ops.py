@@ -63,27 +63,28 @@ class LinearFn(Function):
 class FFNFn(Function):
     """y = dropout(act(x @ W1.T + b1) @ W2.T + b2, p) + x - the feed-forward block in front of its LayerNorm
     (reference vilbert.py:500-503 + :513-517 and the image / connection twins), as ONE autograd node.
-    Backward: the dgrad through W1 adds the skip-connection gradient in its GEMM epilogue (no torch add). (The
-    GELU backward stays a separate HBM-bound pass: folded into the dgrad epilogue its erf + exp per element
-    pushed the GEMM kernels from 128 to 256 VGPRs + scratch - measured -6 % on the whole step.)"""
+    Backward: the dgrad through W1 adds the skip-connection gradient in its GEMM epilogue (no torch add). The
+    activation backward is fused too: the forward epilogue of the up-projection stores act'(pre-activation) next to
+    the activation (one extra exp per element where erf is computed anyway) and the dgrad through W2 multiplies by
+    it in its epilogue - no erf / exp in any backward kernel, no separate elementwise pass over [M, intermediate]."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act, drop_p):
         seed = next_seed() if drop_p > 0.0 else 0
-        h, pre = ops.linear_fwd(x, [w1], [b1], act, None, want_preact=True)
+        h, dact = ops.linear_fwd(x, [w1], [b1], act, None, want_act_grad=True)
         y, _ = ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)
-        ctx.save_for_backward(x, pre, h, w1, w2)
+        ctx.save_for_backward(x, dact, h, w1, w2)
         ctx.act, ctx.drop = act, (drop_p, seed)
         ctx.has_bias = (b1 is not None, b2 is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, pre, h, w1, w2 = ctx.saved_tensors
+        x, dact, h, w1, w2 = ctx.saved_tensors
         dy = dy.contiguous()
         dyd = ops.dropout(dy, ctx.drop[0], ctx.drop[1]) if ctx.drop[0] > 0.0 else dy
         inter, hidden = w1.shape[0], w1.shape[1]
-        dpre = ops.act_bwd(ops.linear_bwd_input(dyd, [w2], inter), pre, ctx.act)
+        dpre = ops.linear_bwd_input(dyd, [w2], inter, mul=dact)
         dw2 = db2 = dw1 = db1 = dx = None
         if ctx.needs_input_grad[3] or (ctx.has_bias[1] and ctx.needs_input_grad[4]):
             (dw2,), (db2,) = ops.linear_bwd_weight(dyd, h, 1, w2.shape[0], [ctx.has_bias[1] and ctx.needs_input_grad[4]])

@@ -58,8 +58,11 @@ def _row_view(x, K):
     return x.view(-1, K), K, tuple(x.shape[:-1])
 
 
-def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0):
+def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0,
+               want_act_grad=False):
     """act(x @ cat(weights).T + cat(biases)) (+ residual).
+    want_act_grad: the second return value is act'(pre-activation) instead of the pre-activation (the backward
+    of the activation then is one multiply in the epilogue of linear_bwd_input(mul=...)).
 
     x: [..., K] (the last dim must be contiguous; a uniform row stride is allowed, e.g. the first-token
     view ``h[:, 0]`` of the poolers). weights: list of [n, K] with equal n; biases: list of [n] or None.
@@ -76,7 +79,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     M = x2.shape[0]
     n_out = nseg * seg_n
     y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
-    pre = torch.empty_like(y) if want_preact else None
+    pre = torch.empty_like(y) if (want_preact or want_act_grad) else None
     a = N.LinearArgs()
     a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
     a.A, a.lda = N.dev_f32(x2, "linear input"), lda
@@ -94,7 +97,9 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
         if residual.numel() != M * n_out:
             raise RuntimeError("linear: residual shape mismatch")
         a.residual, a.ldr = N.dev_f32(residual, "linear residual"), n_out
-    if pre is not None:
+    if pre is not None and want_act_grad:
+        a.act_grad, a.ldg = pre.data_ptr(), n_out
+    elif pre is not None:
         a.preact, a.ldp = pre.data_ptr(), n_out
     a.act = N.ACT_CODES[act]
     a.dropout_p, a.seed = float(drop_p), int(seed)
@@ -103,9 +108,10 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     return y, pre
 
 
-def linear_bwd_input(dy, weights, in_features, residual=None):
-    """dX = dY @ cat(weights) + residual for dY [..., nseg*n]; returns [..., in_features].
-    residual: a gradient of the same shape arriving over a skip connection (added in the GEMM epilogue)."""
+def linear_bwd_input(dy, weights, in_features, residual=None, mul=None):
+    """dX = (dY @ cat(weights) + residual) * mul for dY [..., nseg*n]; returns [..., in_features].
+    residual: a gradient of the same shape arriving over a skip connection (added in the GEMM epilogue);
+    mul: elementwise multiplier of the same shape (the saved activation derivative of the producing layer)."""
     nseg, seg_n = len(weights), weights[0].shape[0]
     dy = _contig(dy)
     M = dy.numel() // (nseg * seg_n)
@@ -123,6 +129,11 @@ def linear_bwd_input(dy, weights, in_features, residual=None):
         if residual.numel() != M * in_features:
             raise RuntimeError("linear_bwd_input: residual shape mismatch")
         a.residual, a.ldr = N.dev_f32(residual, "linear residual grad"), in_features
+    if mul is not None:
+        mul = _contig(mul)
+        if mul.numel() != M * in_features:
+            raise RuntimeError("linear_bwd_input: multiplier shape mismatch")
+        a.mul, a.ldm = N.dev_f32(mul, "linear activation derivative"), in_features
     _timed(lambda: N.check(N.lib().vb_linear_bwd_input(N.stream_ptr(), ctypes.byref(a)), "vb_linear_bwd_input"),
            2.0 * M * nseg * seg_n * in_features)
     return dx
