@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="(train, 1 GPU) also time the step fed from HOST numpy batches through the device input "
                          "pipeline (pinned double-buffered H2D + vb_concap_finish_batch): the PCIe-inclusive rate")
+    ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-shape GEMM time of the profiled step "
+                    "(stderr; HIP events around every launch, single stream)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even at world size 1 "
                     "(exercises the RCCL bucket path on a single GPU)")
     args = ap.parse_args()
@@ -321,6 +323,9 @@ def main():
     torch.cuda.synchronize()
     gemm_ms, gemm_flops, gemm_launches = ops.profile_linear(False)
     _vb.set_two_streams(two)
+    if args.gemm_breakdown and rank == 0:
+        for tag, n, ms, tf in ops.profile_breakdown():
+            print("gemm %-6s M=%6d N=%6d K=%6d nseg=%d  x%3d  %8.3f ms  %6.1f TF" % (tag + (n, ms, tf)), file=sys.stderr)
 
     if rank == 0:
         bert_f, total_f = model_flops_per_sample(cfg, N_TOK, n_reg, "vltasks" if args.mode == "fwd" else "pretraining")

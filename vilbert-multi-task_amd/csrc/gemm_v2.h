@@ -208,22 +208,24 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
         b_krem = k0 - b_seg * p.bseg;
     }
 
-    f32x4 ra[SA], rb[SB];
+    // Staging registers: NSET sets of one K tile each. A tile loaded in step t is written to LDS in step t + NSET
+    // (its set is then reloaded), i.e. the loads of tile t + NSET + 2 are issued in step t: NSET = 1 gives a global
+    // load one K step of latency, NSET = 2 two steps (up to 96 x 128 tiles, where the registers allow it).
+    constexpr int NSET = 1;   // (2 measured: no gain where it fits the registers - the loads are not latency-exposed)
+    f32x4 ra[NSET][SA], rb[NSET][SB];
     // staging, one float4 slot at a time (u < SA: A slots, then B slots) so that the K loop can place every memory
     // instruction by hand between two MFMAs
-    auto load_slot = [&](int u) {
+    auto load_slot = [&](int u, int set) {
         if (u < SA) {
-            ra[u] = *reinterpret_cast<const f32x4*>(ga[u]);
+            ra[set][u] = *reinterpret_cast<const f32x4*>(ga[u]);
             if (ABL != 5) ga[u] += a_stepv;
-            if (ABL == 3) asm volatile("" ::"v"(ra[u]));
         } else if (B_KC) {
-            rb[u - SA] = *reinterpret_cast<const f32x4*>(gb[u - SA]);
+            rb[set][u - SA] = *reinterpret_cast<const f32x4*>(gb[u - SA]);
             if (ABL != 5) gb[u - SA] += ABL == 6 ? 2048 : V2_BK;
-            if (ABL == 3) asm volatile("" ::"v"(rb[u - SA]));
         } else {
             // segments stacked along K (dgrad through stacked weights); bseg is a multiple of 16
             const float* __restrict__ bb = p.B[b_seg] + (long)b_krem * p.ldb;
-            rb[u - SA] = *reinterpret_cast<const f32x4*>(bb + b_off[u - SA]);
+            rb[set][u - SA] = *reinterpret_cast<const f32x4*>(bb + b_off[u - SA]);
             if (u == SA + SB - 1) {
                 b_krem += V2_BK;
                 if (b_krem >= p.bseg) { b_krem = 0; ++b_seg; }
@@ -232,23 +234,23 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
     };
     const bool a_last_ok = (BM * 4) % 256 == 0 || tid + 256 * (SA - 1) < BM * 4;
     const bool b_last_ok = (BN * 4) % 256 == 0 || tid + 256 * (SB - 1) < BN * 4;
-    auto store_slot = [&](int u, float* __restrict__ st) {
+    auto store_slot = [&](int u, float* __restrict__ st, int set) {
         // slots past the end of a 96-row tile (1.5 float4 per thread) go to the dump area instead of branching
         if (u < SA) {
             float* dst = (u + 1 < SA || a_last_ok) ? st + la[u] : smem + Cfg::DUMP + tid * 4;
-            *reinterpret_cast<f32x4*>(dst) = ra[u];
+            *reinterpret_cast<f32x4*>(dst) = ra[set][u];
         } else {
             float* dst = (u + 1 < SA + SB || b_last_ok) ? st + Cfg::A_SZ + lb[u - SA] : smem + Cfg::DUMP + tid * 4;
-            *reinterpret_cast<f32x4*>(dst) = rb[u - SA];
+            *reinterpret_cast<f32x4*>(dst) = rb[set][u - SA];
         }
     };
-    auto load_tile = [&]() {
+    auto load_tile = [&](int set) {
 #pragma unroll
-        for (int u = 0; u < SA + SB; ++u) load_slot(u);
+        for (int u = 0; u < SA + SB; ++u) load_slot(u, set);
     };
-    auto store_tile = [&](float* __restrict__ st) {
+    auto store_tile = [&](float* __restrict__ st, int set) {
 #pragma unroll
-        for (int u = 0; u < SA + SB; ++u) store_slot(u, st);
+        for (int u = 0; u < SA + SB; ++u) store_slot(u, st, set);
     };
 
     // ---- fragment reads ----------------------------------------------------------------------------------------
@@ -277,14 +279,15 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const unsigned long long t_start = p.dbg != nullptr ? __builtin_readcyclecounter() : 0ull;
-    // ---- prologue: tiles 0, 1 into stages 0, 1; tile 2 in flight ---------------------------------------------
-    load_tile();
-    store_tile(smem);
+    // ---- prologue: tiles 0, 1 into stages 0, 1; tiles 2 .. NSET + 1 in flight ----------------------------------
+    load_tile(0);
+    store_tile(smem, 0);
     if (nk > 1) {
-        load_tile();
-        store_tile(smem + Cfg::STAGE);
+        load_tile(0);
+        store_tile(smem + Cfg::STAGE, 0);
     }
-    if (nk > 2) load_tile();
+    if (nk > 2) load_tile(0);
+    if (NSET == 2 && nk > 3) load_tile(1);
     __syncthreads();
 
     // fragment registers: first-half A tiles and all B tiles are double buffered (set = K step parity), the
@@ -344,8 +347,8 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
             mfma_at(m, P);
             const int u = m / SPREAD;
             if (m % SPREAD == 0 && u < UNITS) {
-                if (u < NU) { if (ABL != 1 && ABL != 3) store_slot(u, sw); }
-                else if (u < 2 * NU) { if (ABL != 1 && ABL != 4) load_slot(u - NU); }
+                if (u < NU) { if (ABL != 1) store_slot(u, sw, NSET == 2 ? P : 0); }
+                else if (u < 2 * NU) { if (ABL != 1 && ABL != 4) load_slot(u - NU, NSET == 2 ? P : 0); }
                 else if (u < 2 * NU + TMa) afa[P ^ 1][u - 2 * NU] = read_a(sn, u - 2 * NU);
                 else bfr[P ^ 1][u - 2 * NU - TMa] = read_b(sn, u - 2 * NU - TMa);
             }
@@ -359,12 +362,13 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
         cur = nxt;
     };
     // Tail steps (the last <= 4 of a tile): same data flow with run-time conditions, fragment set 0 is current.
-    auto tail_step = [&](bool do_store, bool do_load, bool do_next) {
+    auto tail_step = [&](bool do_store, bool do_load, bool do_next, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         const float* __restrict__ sc = smem + cur * Cfg::STAGE;
         const int nxt = cur == V2_STAGES - 1 ? 0 : cur + 1;
         const int nn = nxt == V2_STAGES - 1 ? 0 : nxt + 1;
-        if (do_store) store_tile(smem + nn * Cfg::STAGE);
-        if (do_load) load_tile();
+        if (do_store) store_tile(smem + nn * Cfg::STAGE, SET);
+        if (do_load) load_tile(SET);
 #pragma unroll
         for (int i = 0; i < TMb; ++i) afb[i] = read_a(sc, TMa + i);
         if (do_next) {
@@ -390,11 +394,14 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
         cur = nxt;
     };
     int t = 0;
-    for (; t + 4 < nk; t += 2) {
+    for (; t + 3 + NSET < nk; t += 2) {   // both steps issue loads: tile (t + 1) + NSET + 2 must exist
         full_step(std::integral_constant<int, 0>{});
         full_step(std::integral_constant<int, 1>{});
     }
-    for (; t < nk; ++t) tail_step(t + 2 < nk, t + 3 < nk, t + 1 < nk);
+    for (; t < nk; ++t) {
+        if (NSET == 2 && (t & 1)) tail_step(t + 2 < nk, t + 2 + NSET < nk, t + 1 < nk, std::integral_constant<int, NSET - 1>{});
+        else tail_step(t + 2 < nk, t + 2 + NSET < nk, t + 1 < nk, std::integral_constant<int, 0>{});
+    }
 
     if (p.dbg != nullptr && blockIdx.x == 128 && blockIdx.y == 0 && tid == 0) {
         p.dbg[0] = __builtin_readcyclecounter() - t_start;   // main-loop span of one block, shader cycles

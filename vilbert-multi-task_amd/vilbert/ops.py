@@ -13,25 +13,41 @@ from . import _native as N
 
 # Optional per-launch timing of the GEMM kernel (bench.py's roofline leg): when enabled every GEMM
 # launch (forward, dgrad, wgrad) is bracketed by HIP events recorded on the launch stream.
-_PROFILE = {"on": False, "events": [], "flops": 0.0}
+_PROFILE = {"on": False, "events": [], "flops": 0.0, "tags": []}
 
 
 def profile_linear(enable):
     """enable=True starts collecting; enable=False stops and returns (total_ms, total_flops, launches)."""
     if enable:
-        _PROFILE.update(on=True, events=[], flops=0.0)
+        _PROFILE.update(on=True, events=[], flops=0.0, tags=[])
         return None
     _PROFILE["on"] = False
     torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b in _PROFILE["events"])
+    times = [a.elapsed_time(b) for a, b in _PROFILE["events"]]
+    ms = sum(times)
     out = (ms, _PROFILE["flops"], len(_PROFILE["events"]))
+    # per-shape breakdown of the last profiled region: {(kind, M, N, K, nseg): [launches, ms, flops]}
+    by_shape = {}
+    for (tag, fl), t in zip(_PROFILE["tags"], times):
+        e = by_shape.setdefault(tag, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += t
+        e[2] += fl
+    _PROFILE["by_shape"] = by_shape
     _PROFILE["events"] = []
     return out
 
 
-def _timed(fn, flops):
+def profile_breakdown():
+    """Per-shape GEMM time of the last profile_linear region, slowest total first."""
+    rows = sorted(_PROFILE.get("by_shape", {}).items(), key=lambda kv: -kv[1][1])
+    return [(tag, n, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0) for tag, (n, ms, fl) in rows]
+
+
+def _timed(fn, flops, tag=None):
     if not _PROFILE["on"]:
         return fn()
+    _PROFILE["tags"].append((tag, flops))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     out = fn()
@@ -104,7 +120,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     a.act = N.ACT_CODES[act]
     a.dropout_p, a.seed = float(drop_p), int(seed)
     _timed(lambda: N.check(N.lib().vb_linear_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd"),
-           2.0 * M * n_out * K)
+           2.0 * M * n_out * K, ("fwd", M, seg_n, K, nseg))
     return y, pre
 
 
@@ -135,7 +151,7 @@ def linear_bwd_input(dy, weights, in_features, residual=None, mul=None):
             raise RuntimeError("linear_bwd_input: multiplier shape mismatch")
         a.mul, a.ldm = N.dev_f32(mul, "linear activation derivative"), in_features
     _timed(lambda: N.check(N.lib().vb_linear_bwd_input(N.stream_ptr(), ctypes.byref(a)), "vb_linear_bwd_input"),
-           2.0 * M * nseg * seg_n * in_features)
+           2.0 * M * nseg * seg_n * in_features, ("dgrad", M, seg_n, in_features, nseg))
     return dx
 
 
@@ -167,7 +183,7 @@ def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
         dws.append(dw)
         dbs.append(db)
     _timed(lambda: N.check(N.lib().vb_linear_bwd_weight(N.stream_ptr(), ctypes.byref(a)), "vb_linear_bwd_weight"),
-           2.0 * M * nseg * seg_n * K)
+           2.0 * M * nseg * seg_n * K, ("wgrad", M, seg_n, K, nseg))
     return dws, dbs
 
 
