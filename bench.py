@@ -6,8 +6,13 @@ One "step" = one pass of the hot path (BertModel encoder + all heads) over one s
 36 regions x 2048 features + 36 tokens, model bert_base_6layer_6conect.json, random (seeded) weights,
 inputs resident in HBM before the timed region. Prints ONE JSON line on rank 0.
 
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); per-GPU batch is fixed
-(weak scaling); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+N > 1: one rank per GPU over RCCL. Either launch it as the driver does (python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...) or just run `python bench.py --gpus N`: without RANK in the environment
+the script re-executes itself through torch.distributed.run on 127.0.0.1. The headline value is weak scaling (fixed
+per-GPU batch 256, BASELINE.json's metric); the same line also carries the reference's own data-parallel
+configuration (BASELINE configs[2]: GLOBAL batch 512 divided over the ranks, reference train_concap.py:290-294) as
+"global512" and - on one GPU - the north-star forward point (batch 512) as "fwd_b512". The timed regions are
+bracketed by barrier + synchronize and the max over ranks is taken.
 """
 import argparse
 import json
@@ -138,6 +143,10 @@ def cpu_baseline(cfg, mode, budget_s=25.0):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(B / med, 2), "unit": "samples/s", "cores": best_threads, "kind": "port",
+            "why_port": "the reference source tree (/root/reference) does not exist on the GPU box; the oracle is its "
+                        "line-by-line restatement, pinned against the real reference by tests/golden + "
+                        "tests/test_oracle_vs_reference.py (BASELINE.md section 3 plans the reference's own code at "
+                        "batch 16 - same torch CPU ops, same threads)",
             "sample": "oracle/vilbert_oracle.py %s, batch %d, median of %d runs (min %.3fs max %.3fs); torch %s "
                       "CPU fp32, %d threads used of %d host cores" %
                       ("fwd+bwd (pre-training losses, autograd)" if train else "forward (VILBertForVLTasks, all heads)",
@@ -166,6 +175,9 @@ def main():
                          "pipeline (pinned double-buffered H2D + vb_concap_finish_batch): the PCIe-inclusive rate")
     ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-shape GEMM time of the profiled step "
                     "(stderr; HIP events around every launch, single stream)")
+    ap.add_argument("--global-batch", type=int, default=0, help="GLOBAL batch divided over the ranks (strong scaling; the "
+                    "reference's own data-parallel mode, train_concap.py:290-294) instead of a fixed per-GPU batch")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the global512 / fwd_b512 legs of the default line")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even at world size 1 "
                     "(exercises the RCCL bucket path on a single GPU)")
     args = ap.parse_args()
@@ -173,8 +185,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_ddp:
@@ -188,64 +212,119 @@ def main():
     CONFIG, N_TOK, N_REG = args.config, args.tokens, args.regions
     cfg = BertConfig.from_json_file(os.path.join(ROOT, "vilbert-multi-task_amd", "config", CONFIG)).to_dict()
     B = args.batch
-    if args.mode == "fwd":
-        x = synthetic_batch(cfg, B, N_TOK, N_REG, 7 + rank, False)
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be divisible by the number of ranks")
+        B = args.global_batch // world
+
+    def forward_workload(batch):
+        """(step, inputs dict, model): VILBertForVLTasks forward, eval + no_grad."""
+        xb = synthetic_batch(cfg, batch, N_TOK, N_REG, 7 + rank, False)
         names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
                  "image_attention_mask", "co_attention_mask"]
-        inputs = tuple(x[n].to(device) for n in names)
-        model = build_model(cfg, "vltasks", device).eval()
-        n_reg = N_REG
+        inp = tuple(xb[n].to(device) for n in names)
+        net = build_model(cfg, "vltasks", device).eval()
 
-        def step():
+        def fstep():
             with torch.no_grad():
-                return model(*inputs)
-    else:
-        # train_concap.py step (reference :523-585): BertForMultiModalPreTraining in train mode (dropout
-        # on), the loader's shapes (36 regions + 1 global-mean region row -> R = 37, 36 tokens, 36x1601
-        # region targets), loss = masked-LM + masked-region KL + alignment, backward, gradient
-        # all-reduce (N > 1), AdamW step.
-        n_reg = N_REG + 1
-        x = synthetic_batch(cfg, B, N_TOK, n_reg, 7 + rank, True)
+                return net(*inp)
+        return fstep, xb, net
+
+    train_state = {}
+
+    def train_workload(batch):
+        """train_concap.py step (reference :523-585): BertForMultiModalPreTraining in train mode (dropout on), the
+        loader's shapes (36 regions + 1 global-mean region row -> R = 37, 36 tokens, 36x1601 region targets), loss =
+        masked-LM + masked-region KL + alignment, backward, gradient all-reduce (N > 1), AdamW step. The model /
+        optimizer are built once and shared by the legs that only change the batch."""
+        xb = synthetic_batch(cfg, batch, N_TOK, N_REG + 1, 7 + rank, True)
         names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
                  "image_attention_mask", "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
-        inputs = tuple(x[n].to(device) for n in names)
-        model = build_model(cfg, "pretraining", device).train()
-        if world > 1 or args.force_ddp:
-            from vilbert.distributed import DistributedDataParallel
-            model = DistributedDataParallel(model)
-        decay = [p for n, p in model.named_parameters() if p.requires_grad and not any(
-            k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
-        no_decay = [p for n, p in model.named_parameters() if p.requires_grad and any(
-            k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
-        from vilbert.optim import AdamW   # native multi-tensor launch, pytorch-transformers 1.0.0 semantics
-        opt = AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}],
-                    lr=1e-4, betas=(0.9, 0.98))   # train_concap.py:465-470
+        inp = tuple(xb[n].to(device) for n in names)
+        if not train_state:
+            net = build_model(cfg, "pretraining", device).train()
+            if world > 1 or args.force_ddp:
+                from vilbert.distributed import DistributedDataParallel
+                net = DistributedDataParallel(net)
+            decay = [p for n, p in net.named_parameters() if p.requires_grad and not any(
+                k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+            no_decay = [p for n, p in net.named_parameters() if p.requires_grad and any(
+                k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+            from vilbert.optim import AdamW   # native multi-tensor launch, pytorch-transformers 1.0.0 semantics
+            train_state["model"] = net
+            train_state["opt"] = AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}],
+                                       lr=1e-4, betas=(0.9, 0.98))   # train_concap.py:465-470
+        net, optim = train_state["model"], train_state["opt"]
 
-        def step():
-            opt.zero_grad(set_to_none=True)
-            lm, img, nsp = model(*inputs)
+        def tstep():
+            optim.zero_grad(set_to_none=True)
+            lm, img, nsp = net(*inp)
             loss = lm.mean() + img.mean() + nsp.mean()
             loss.backward()
-            opt.step()
+            optim.step()
             return loss
+        return tstep, xb, net
+
+    if args.mode == "fwd":
+        step, x, model = forward_workload(B)
+        n_reg = N_REG
+    else:
+        step, x, model = train_workload(B)
+        n_reg = N_REG + 1
+        opt = train_state["opt"]
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, warmup, steps):
+        """warmup untimed calls, then `steps` calls bracketed by barrier + synchronize; max over the ranks (seconds)."""
+        for _ in range(warmup):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    elapsed = timed(step, args.warmup, args.steps)
+
+    # Extra legs of the default line (same process, after the headline timing):
+    #  * global512 - BASELINE configs[2] as the reference runs it: GLOBAL batch 512 split over the ranks (64 per GPU at
+    #    N = 8, reference train_concap.py:290-294) - strong scaling, reported beside the weak-scaling headline;
+    #  * fwd_b512 (one GPU) - the north-star target point: 6L/6C co-attention forward at batch 512.
+    extra = {}
+    default_line = args.mode == "train" and CONFIG == "bert_base_6layer_6conect.json" and not args.global_batch \
+        and args.batch == 256 and args.gemm_mode == "f32" and not args.no_extra_legs
+    if default_line and 512 % world == 0:
+        gstep, gx, _ = train_workload(512 // world)
+        n_g = max(3, args.steps // 2)
+        g_dt = timed(gstep, 2, n_g)
+        extra["global512"] = {"value": round(512 * n_g / g_dt, 2), "unit": "samples/s", "global_batch": 512,
+                              "per_gpu_batch": 512 // world, "ms_per_step": round(1e3 * g_dt / n_g, 3), "steps": n_g,
+                              "scaling": "strong", "note": "BASELINE configs[2]: train_concap step at GLOBAL batch 512 "
+                              "divided over the ranks (reference train_concap.py:290-294)"}
+        del gstep, gx
+    if default_line and world == 1:
+        fstep, _, fmodel = forward_workload(512)
+        n_f = max(5, args.steps // 2)
+        f_dt = timed(fstep, 2, n_f)
+        _, f_total = model_flops_per_sample(cfg, N_TOK, N_REG, "vltasks")
+        f_tf = 512 * n_f / f_dt * f_total / 1e12
+        extra["fwd_b512"] = {"value": round(512 * n_f / f_dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * f_dt / n_f, 3),
+                             "steps": n_f, "model_tflops": round(f_tf, 2),
+                             "frac_of_fp32_mfma_peak": round(f_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "note": "north-star target point: VILBertForVLTasks forward (eval, no_grad, all heads), "
+                                     "batch 512, T = R = 36, one GPU; target >= 0.40 of the MFMA peak"}
+        del fstep, fmodel
+        torch.cuda.empty_cache()
 
     # The same workload with the opt-in bf16x6 GEMM mode (fp32 operands split into 3 bf16 planes, six MFMA
     # products per fp32 product; passes the same parity tests) - reported beside the primary number.
@@ -342,22 +421,25 @@ def main():
         sps = world * B * args.steps / elapsed
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_note = None, "not measured"
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
+        if not os.path.isfile(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
         if os.path.isfile(tpath):
             # HBM bytes per launch cannot be read from inside the process; this is the rocprofv3 PMC
             # measurement (FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction) of the dominant forward
             # GEMM shape, committed under profiles/
             t0 = json.load(open(tpath))["launches"][0]
             traffic = t0["hbm_bytes_corrected"]
-            traffic_note = "rocprofv3 PMC, %s M=%d N=%d K=%d: %.0f MB per launch vs %.0f MB algorithmic (profiles/r01_gemm_traffic.json)" % (
-                t0["kernel"], t0["M"], t0["N"], t0["K"], traffic / 1e6, t0["algorithmic_bytes"] / 1e6)
+            traffic_note = "rocprofv3 PMC, %s M=%d N=%d K=%d: %.0f MB per launch vs %.0f MB algorithmic (profiles/%s)" % (
+                t0["kernel"], t0["M"], t0["N"], t0["K"], traffic / 1e6, t0["algorithmic_bytes"] / 1e6, os.path.basename(tpath))
         line = {
             "metric": "samples/sec (%d regions, %d tokens) ViLBERT-%s %s" %
                       (N_REG, N_TOK, "base 6L/6C" if CONFIG == "bert_base_6layer_6conect.json" else CONFIG,
                        "forward" if args.mode == "fwd" else "fwd+bwd"),
             "value": round(sps, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
+            "dtype": "f32",
             "data": "synthetic (seeded 36x2048 region features + 36 token ids, random-init weights)",
             "config": {"workload": "%s %s, batch %d per GPU, T=%d R=%d" %
                                    (CONFIG, "forward-only (eval, no_grad), VILBertForVLTasks incl. all heads"
@@ -365,13 +447,14 @@ def main():
                                     "train_concap step: BertForMultiModalPreTraining fwd+bwd (dropout on) + "
                                     "grad all-reduce + AdamW, %d regions + 1 global row" % N_REG, B, N_TOK, n_reg),
                        "per_gpu_batch": B, "global_batch": B * world,
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "visible_gpus": torch.cuda.device_count(),
                        "gflop_per_sample_model": round(mult * total_f / 1e9, 3),
                        "gflop_per_sample_executed": round(mult * exec_f / 1e9, 3),
                        "gflop_per_sample_bertmodel": round(mult * bert_f / 1e9, 3)},
             "model_tflops": round(sps / world * mult * exec_f / 1e12, 2),
             "model_frac_of_fp32_mfma_peak": round(sps / world * mult * exec_f / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_v2_kernel (v_mfma_f32_16x16x4_f32; ragged launches: "
+                                                    "gemm_f32_kernel, v_mfma_f32_32x32x2_f32)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": traffic_note,
@@ -382,6 +465,7 @@ def main():
                          "flops_per_launch_avg": round(gemm_flops / max(gemm_launches, 1), 0)},
         }
         line["config"]["gemm_mode"] = args.gemm_mode
+        line.update(extra)
         if alt is not None:
             line["alt_gemm_mode"] = alt
         if host_leg is not None:

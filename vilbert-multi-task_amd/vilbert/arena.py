@@ -1,0 +1,161 @@
+"""Gradient arena: every parameter gradient of a model lives at a FIXED address inside one flat fp32 buffer.
+
+Why (MI355X, 288 GB HBM - the 1 GB of gradients is nothing, its traffic and launch count are):
+  * the wgrad GEMM (split-K atomics), the fused bias-gradient column sums and the embedding scatter all ADD into
+    zero-filled memory: with per-call ``torch.zeros`` targets that was ~250 fill launches + 1 GB of allocator churn
+    per step; the arena is zero-filled by ONE memset at the first gradient write of a backward pass;
+  * ``param.grad`` becomes a view of the arena (autograd "steals" the tensor a backward node returns, so returning a
+    fresh alias of the arena slice costs no copy): the data-parallel buckets (distributed.py) ARE arena ranges - no
+    pack copy before the all-reduce, no copy back - and the optimizer's pointer table never changes from step to step,
+    which together with the device-side dropout counter makes the whole training step HIP-graph capturable;
+  * a parameter that receives several contributions in one backward (the word-embedding matrix is also the MLM
+    decoder, reference vilbert.py:1463-1469) is accumulated in place by the producing kernels instead of by a torch add.
+
+Protocol used by autograd_ops.py (``claim`` / ``result``):
+    view, mode = arena.claim(param)       # None -> parameter not managed, caller uses a private buffer
+      mode "fresh":  first contribution of this backward pass and ``param.grad is None``: the kernel adds into the
+                     zeroed view and the Function RETURNS an alias of it (autograd installs it as ``param.grad``);
+      mode "accum":  a later contribution of the same pass, or ``param.grad`` already IS the arena view (gradient
+                     accumulation over micro-batches): the kernel adds into the view, the Function returns ``None``.
+If ``param.grad`` is some foreign tensor (a user assigned it), the parameter is left to plain autograd.
+"""
+import torch
+
+_BY_PTR = {}        # param.data_ptr() -> (arena, index)
+
+
+def lookup(param):
+    e = _BY_PTR.get(param.data_ptr())
+    if e is None or e[0].params[e[1]].shape != param.shape:
+        return None
+    return e
+
+
+class GradArena(object):
+    def __init__(self, params, align_elems=4):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("GradArena needs at least one parameter")
+        dev, dt = params[0].device, params[0].dtype
+        if dt != torch.float32:
+            raise RuntimeError("GradArena holds fp32 gradients")
+        self._cuda = dev.type == "cuda"     # (CPU tensors only in the gloo tests of the data-parallel wrapper)
+        self.params, self.offsets, seen, total = [], [], set(), 0
+        for p in params:
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            if p.device != dev or p.dtype != dt:
+                raise RuntimeError("GradArena: all parameters must live on one device in fp32")
+            self.params.append(p)
+            self.offsets.append(total)
+            total += (p.numel() + align_elems - 1) // align_elems * align_elems   # every slice stays 16-byte aligned
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+        self._written = set()          # indices claimed in the running backward pass
+        self._pass_id = None           # autograd graph-task id of the running pass
+        self._clean = True             # flat is all zeros
+        self._zero_stream = None
+        self._zero_event = None
+        self._listeners = []           # objects with .arena_written(index) / .arena_backward_done()
+        self._taken_over = 0
+        for i, p in enumerate(self.params):
+            old = _BY_PTR.get(p.data_ptr())
+            if old is not None and old[0] is not self:
+                # a newer arena (e.g. the data-parallel wrapper's bucket layout) takes the parameter over; an arena
+                # that lost all its parameters frees its buffer
+                old[0]._taken_over += 1
+                if old[0]._taken_over >= len(old[0].params):
+                    old[0].flat, old[0].views = None, []
+            _BY_PTR[p.data_ptr()] = (self, i)
+
+    # ------------------------------------------------------------------------------------------------------
+    def add_listener(self, obj):
+        self._listeners.append(obj)
+
+    def release(self):
+        """Stop managing the parameters (their current .grad tensors stay valid views of the buffer)."""
+        for p in self.params:
+            e = _BY_PTR.get(p.data_ptr())
+            if e is not None and e[0] is self:
+                del _BY_PTR[p.data_ptr()]
+
+    def owns(self, param, index):
+        g = param.grad
+        return g is not None and g.data_ptr() == self.views[index].data_ptr()
+
+    def _begin_pass(self):
+        """First claim of a backward pass: zero the arena unless gradients are being accumulated into it."""
+        self._written.clear()
+        accumulating = any(self.owns(p, i) for i, p in enumerate(self.params))
+        if not accumulating:
+            if not self._clean:
+                self.flat.zero_()
+            if self._cuda:
+                self._zero_stream = torch.cuda.current_stream(self.flat.device)
+                self._zero_event = torch.cuda.Event()
+                self._zero_event.record(self._zero_stream)
+        self._clean = False
+        self._accumulating = accumulating
+        torch.autograd.Variable._execution_engine.queue_callback(self._end_pass)
+
+    def _end_pass(self):
+        self._pass_id = None
+        self._written.clear()
+        for l in self._listeners:
+            l.arena_backward_done()
+
+    def claim(self, param):
+        """-> (view, mode) with mode in {"fresh", "accum"}, or (None, None) if the caller should use its own buffer."""
+        e = lookup(param)
+        if e is None or e[0] is not self:
+            return None, None
+        i = e[1]
+        task = torch._C._current_graph_task_id()
+        if task == -1:
+            return None, None                      # not inside a backward pass (manual call of a backward op)
+        if self._pass_id != task:
+            self._pass_id = task
+            self._begin_pass()
+        # writers on another stream than the one that zero-filled the arena must wait for the fill
+        if self._cuda and self._zero_event is not None:
+            cur = torch.cuda.current_stream(self.flat.device)
+            if cur != self._zero_stream:
+                cur.wait_event(self._zero_event)
+        if i in self._written:
+            return self.views[i], "accum"
+        g = param.grad
+        if g is None:
+            if self._accumulating:
+                self.views[i].zero_()              # a stale slice next to slices that are being accumulated
+            self._written.add(i)
+            return self.views[i], "fresh"
+        if g.data_ptr() == self.views[i].data_ptr():
+            self._written.add(i)
+            return self.views[i], "accum"
+        return None, None
+
+    def alias(self, index):
+        """A fresh tensor object over the slice (autograd steals it: use_count 1, no copy)."""
+        o, p = self.offsets[index], self.params[index]
+        return self.flat[o:o + p.numel()].view(p.shape)
+
+
+def claim(param):
+    """(view, mode, arena, index) for `param`, or (None, None, None, None)."""
+    e = lookup(param)
+    if e is None:
+        return None, None, None, None
+    view, mode = e[0].claim(param)
+    if view is None:
+        return None, None, None, None
+    return view, mode, e[0], e[1]
+
+
+def result(mode, arena, index, fallback):
+    """What a backward node returns for a parameter whose gradient it wrote through claim()."""
+    if mode == "fresh":
+        return arena.alias(index)
+    if mode == "accum":
+        return None
+    return fallback

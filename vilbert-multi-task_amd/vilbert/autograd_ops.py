@@ -11,6 +11,7 @@ import itertools
 import torch
 from torch.autograd import Function
 
+from . import arena as _arena
 from . import ops
 
 _seed_counter = itertools.count(1)
@@ -23,6 +24,46 @@ def next_seed():
         & 0xFFFFFFFFFFFFFFFF
 
 
+class _Claims(object):
+    """Gradient targets of a group of parameters for one backward node: gradient-arena slices where the arena
+    manages the parameter (the kernels add in place, autograd gets an alias or None - see arena.py), else None
+    (the launcher allocates)."""
+
+    def __init__(self, params, needed):
+        self.c = [(_arena.claim(p) if (n and p is not None) else (None, None, None, None)) for p, n in zip(params, needed)]
+
+    def views(self):
+        return [c[0] for c in self.c]
+
+    def out(self, i, fallback):
+        _view, mode, ar, idx = self.c[i]
+        return _arena.result(mode, ar, idx, fallback)
+
+    def fresh_or_none(self, i):
+        """target for a kernel that OVERWRITES (LayerNorm column sums): only a fresh (zeroed, first-writer) slice."""
+        return self.c[i][0] if self.c[i][1] == "fresh" else None
+
+    def finish_overwrite(self, i, value):
+        """value was computed by an overwriting kernel; returns what the backward node hands to autograd."""
+        view, mode, ar, idx = self.c[i]
+        if mode == "fresh":
+            return ar.alias(idx)          # written in place
+        if mode == "accum":
+            view.add_(value)
+            return None
+        return value
+
+
+def _wgrad(dy, x, weights, biases_present, need_w, need_b):
+    """dW / db of the stacked segments into their arena slices (or fresh buffers); returns what autograd gets."""
+    nseg, seg_n = len(weights), weights[0].shape[0]
+    cw = _Claims(weights, need_w)
+    cb = _Claims(biases_present, need_b)
+    dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
+    return ([cw.out(s, dws[s]) if need_w[s] else None for s in range(nseg)],
+            [cb.out(s, dbs[s]) if need_b[s] else None for s in range(nseg)])
+
+
 class LinearFn(Function):
     """y = dropout(act(x @ cat(W).T + cat(b)), p) (+ residual). Inputs: x, residual, act, nseg, drop_p, W..., b...
     The dropout mask is regenerated in backward from the saved seed (vb_dropout on the incoming gradient)."""
@@ -33,7 +74,7 @@ class LinearFn(Function):
         seed = next_seed() if drop_p > 0.0 else 0
         y, pre = ops.linear_fwd(x, weights, biases, act, residual, want_preact=act is not None, drop_p=drop_p,
                                 seed=seed)
-        ctx.save_for_backward(x, pre, *weights)
+        ctx.save_for_backward(x, pre, *weights, *[b for b in biases if b is not None])
         ctx.act, ctx.nseg = act, nseg
         ctx.drop = (drop_p, seed)
         ctx.has_bias = [b is not None for b in biases]
@@ -42,8 +83,11 @@ class LinearFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, pre = ctx.saved_tensors[:2]
-        weights = list(ctx.saved_tensors[2:])
-        nseg, seg_n, K = ctx.nseg, weights[0].shape[0], weights[0].shape[1]
+        nseg = ctx.nseg
+        weights = list(ctx.saved_tensors[2:2 + nseg])
+        rest = list(ctx.saved_tensors[2 + nseg:])
+        biases = [rest.pop(0) if h else None for h in ctx.has_bias]
+        seg_n, K = weights[0].shape[0], weights[0].shape[1]
         dy = dy.contiguous()
         dres = dy if ctx.needs_input_grad[1] else None
         if ctx.drop[0] > 0.0:
@@ -52,11 +96,12 @@ class LinearFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dpre, weights, K).view(x.shape)
-        need_w = any(ctx.needs_input_grad[5:5 + nseg])
+        need_w = [bool(ctx.needs_input_grad[5 + s]) for s in range(nseg)]
         need_b = [ctx.has_bias[s] and ctx.needs_input_grad[5 + nseg + s] for s in range(nseg)]
         dws, dbs = [None] * nseg, [None] * nseg
-        if need_w or any(need_b):
-            dws, dbs = ops.linear_bwd_weight(dpre, x, nseg, seg_n, need_b)
+        if any(need_w) or any(need_b):
+            # (the fused launch computes every segment; segments nobody asked for land in scratch buffers)
+            dws, dbs = _wgrad(dpre, x, weights, biases, need_w, need_b)
         return (dx, dres, None, None, None) + tuple(dws) + tuple(dbs)
 
 
@@ -73,26 +118,38 @@ class FFNFn(Function):
         seed = next_seed() if drop_p > 0.0 else 0
         h, dact = ops.linear_fwd(x, [w1], [b1], act, None, want_act_grad=True)
         y, _ = ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)
-        ctx.save_for_backward(x, dact, h, w1, w2)
+        ctx.save_for_backward(x, dact, h, w1, w2, *[b for b in (b1, b2) if b is not None])
         ctx.act, ctx.drop = act, (drop_p, seed)
         ctx.has_bias = (b1 is not None, b2 is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, dact, h, w1, w2 = ctx.saved_tensors
+        x, dact, h, w1, w2 = ctx.saved_tensors[:5]
+        rest = list(ctx.saved_tensors[5:])
+        b1 = rest.pop(0) if ctx.has_bias[0] else None
+        b2 = rest.pop(0) if ctx.has_bias[1] else None
         dy = dy.contiguous()
         dyd = ops.dropout(dy, ctx.drop[0], ctx.drop[1]) if ctx.drop[0] > 0.0 else dy
         inter, hidden = w1.shape[0], w1.shape[1]
         dpre = ops.linear_bwd_input(dyd, [w2], inter, mul=dact)
         dw2 = db2 = dw1 = db1 = dx = None
-        if ctx.needs_input_grad[3] or (ctx.has_bias[1] and ctx.needs_input_grad[4]):
-            (dw2,), (db2,) = ops.linear_bwd_weight(dyd, h, 1, w2.shape[0], [ctx.has_bias[1] and ctx.needs_input_grad[4]])
+        nb2 = bool(ctx.has_bias[1] and ctx.needs_input_grad[4])
+        if ctx.needs_input_grad[3] or nb2:
+            (dw2,), (db2,) = _wgrad(dyd, h, [w2], [b2], [bool(ctx.needs_input_grad[3])], [nb2])
         if ctx.needs_input_grad[0]:
             dx = ops.linear_bwd_input(dpre, [w1], hidden, residual=dy).view(x.shape)
-        if ctx.needs_input_grad[1] or (ctx.has_bias[0] and ctx.needs_input_grad[2]):
-            (dw1,), (db1,) = ops.linear_bwd_weight(dpre, x, 1, inter, [ctx.has_bias[0] and ctx.needs_input_grad[2]])
+        nb1 = bool(ctx.has_bias[0] and ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[1] or nb1:
+            (dw1,), (db1,) = _wgrad(dpre, x, [w1], [b1], [bool(ctx.needs_input_grad[1])], [nb1])
         return dx, dw1, db1, dw2, db2, None, None
+
+
+def _ln_bwd(dy, x, mean, rstd, gamma, beta, need_g, need_b):
+    """LayerNorm backward with dgamma / dbeta written straight into their arena slices when those are fresh."""
+    c = _Claims([gamma, beta], [need_g, need_b])
+    dx, dgamma, dbeta = ops.layernorm_bwd(dy, x, mean, rstd, gamma, c.fresh_or_none(0), c.fresh_or_none(1))
+    return dx, (c.finish_overwrite(0, dgamma) if need_g else None), (c.finish_overwrite(1, dbeta) if need_b else None)
 
 
 class LayerNormFn(Function):
@@ -101,13 +158,13 @@ class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, None, want_stats=True)
-        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, rstd, gamma = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.layernorm_bwd(dy, x, mean, rstd, gamma)
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dx, dgamma, dbeta = _ln_bwd(dy, x, mean, rstd, gamma, beta, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx.view(x.shape), dgamma, dbeta, None
 
 
@@ -199,17 +256,20 @@ class TextEmbedFn(Function):
     def forward(ctx, ids, seg, word, pos, typ, gamma, beta, eps, task_ids, task_emb):
         out, mean, rstd, presum = ops.text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids,
                                                         task_emb, want_stats=True)
-        ctx.save_for_backward(ids, seg, task_ids, presum, mean, rstd, gamma)
-        ctx.shapes = (tuple(word.shape), tuple(pos.shape), tuple(typ.shape),
-                      tuple(task_emb.shape) if task_emb is not None else None)
+        ctx.save_for_backward(ids, seg, task_ids, presum, mean, rstd, gamma, beta, word, pos, typ, task_emb)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        ids, seg, task_ids, presum, mean, rstd, gamma = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.layernorm_bwd(dy, presum, mean, rstd, gamma)
-        ws, ps, ts, ks = ctx.shapes
-        dword, dpos, dtype, dtask = ops.text_embed_bwd(dx, ids, seg, task_ids, ws, ps, ts, ks)
+        ids, seg, task_ids, presum, mean, rstd, gamma, beta, word, pos, typ, task_emb = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dx, dgamma, dbeta = _ln_bwd(dy, presum, mean, rstd, gamma, beta, need[5], need[6])
+        tables = [word, pos, typ, task_emb]
+        want = [bool(need[2]), bool(need[3]), bool(need[4]), bool(task_emb is not None and need[9])]
+        c = _Claims(tables, want)
+        got = ops.text_embed_bwd(dx, ids, seg, task_ids, tuple(word.shape), tuple(pos.shape), tuple(typ.shape),
+                                 tuple(task_emb.shape) if task_emb is not None else None, out=c.views())
+        dword, dpos, dtype, dtask = [(c.out(i, got[i]) if want[i] else None) for i in range(4)]
         return None, None, dword, dpos, dtype, dgamma, dbeta, None, None, dtask
 
 
@@ -218,15 +278,15 @@ class ImageEmbedFn(Function):
     def forward(ctx, feat_proj, loc, w_loc, b_loc, gamma, beta, eps):
         out, mean, rstd, presum = ops.image_embed_ln_fwd(feat_proj, loc, w_loc, b_loc, gamma, beta, eps,
                                                          want_stats=True)
-        ctx.save_for_backward(loc, presum, mean, rstd, gamma)
+        ctx.save_for_backward(loc, presum, mean, rstd, gamma, beta, w_loc, b_loc)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        loc, presum, mean, rstd, gamma = ctx.saved_tensors
-        dsum, dgamma, dbeta = ops.layernorm_bwd(dy, presum, mean, rstd, gamma)
-        hidden = dsum.shape[-1]
-        (dw_loc,), (db_loc,) = ops.linear_bwd_weight(dsum, loc.reshape(-1, 5), 1, hidden, [True])
+        loc, presum, mean, rstd, gamma, beta, w_loc, b_loc = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dsum, dgamma, dbeta = _ln_bwd(dy, presum, mean, rstd, gamma, beta, need[4], need[5])
+        (dw_loc,), (db_loc,) = _wgrad(dsum, loc.reshape(-1, 5), [w_loc], [b_loc], [bool(need[2])], [bool(need[3])])
         return dsum, None, dw_loc, db_loc, dgamma, dbeta, None
 
 

@@ -5,39 +5,44 @@ overlapped / bucketed; train_tasks.py:490-497 ``delay_allreduce=True``): the onl
 path is one gradient all-reduce (average) per optimizer step.
 
 Design for MI355X (8 GPUs, 7 xGMI links per GPU, 288 GB HBM each):
-  * gradients live in a few LARGE flat fp32 buckets (default 256 MiB: a ~1 GB model is 4-5 collectives,
-    big enough to sit on RCCL's bandwidth plateau over xGMI, few enough that launch latency is noise);
-  * buckets are filled in reverse parameter-registration order, i.e. roughly the order backward produces
-    gradients (text layer 11, image layer 5, connection 5, ... embeddings last), and each bucket's
-    all-reduce is issued asynchronously the moment its last gradient arrives, so communication of
-    bucket i overlaps the backward GEMMs of bucket i+1;
-  * parameters that never receive a gradient (``biOutput.q_dense1/2`` always; most task heads under
-    train_tasks) are learnt on the first step and no longer block their bucket; with
-    ``delay_allreduce=True`` nothing is assumed and every bucket is reduced after backward (the
-    reference's choice for multi-task training, where the unused set changes per task);
-  * after the reduce ``param.grad`` is a VIEW into the bucket: no copy back.
+  * ZERO COPY: the buckets are contiguous ranges of the model's gradient arena (arena.py). The backward kernels
+    (wgrad GEMM epilogues, LayerNorm / embedding gradient kernels) write every gradient at its final address inside
+    its bucket, ``param.grad`` is a view of it, the all-reduce runs in place and the optimizer reads the same memory:
+    no pack copy before the collective, no copy back after it (gradients produced by foreign autograd nodes are
+    copied in, the exception);
+  * a few LARGE buckets (default 256 MiB: a ~1 GB model is 4-5 collectives, big enough to sit on RCCL's bandwidth
+    plateau over xGMI, few enough that launch latency is noise), laid out in reverse parameter-registration order,
+    i.e. roughly the order backward produces gradients (text layer 11, image layer 5, connection 5, ... embeddings
+    last); each bucket's all-reduce is issued asynchronously the moment its last expected gradient arrives, so the
+    communication of bucket i overlaps the backward GEMMs of bucket i + 1;
+  * the set of parameters that receive a gradient is learnt per bucket on the first pass (``biOutput.q_dense1/2`` never
+    do; most task heads do not under train_tasks) and tracked as a SET: a bucket is reduced early only when exactly
+    the expected parameters have arrived; a gradient that shows up for a parameter outside that set before the launch
+    simply extends the wait, one that shows up AFTER its bucket was reduced raises (silently averaging a stale slice
+    would corrupt training) - use ``delay_allreduce=True`` (reduce everything after backward, the reference's choice
+    for multi-task training) when the used set changes from step to step.
 Works with any ``torch.distributed`` backend (``nccl`` = RCCL on ROCm; ``gloo`` for the CPU tests).
 """
 import torch
 import torch.distributed as dist
 from torch import nn
 
+from .arena import GradArena
+
 
 class _Bucket(object):
-    def __init__(self, params, device, dtype):
-        self.params = params
-        self.offsets, total = [], 0
-        for p in params:
-            self.offsets.append(total)
-            total += (p.numel() + 3) // 4 * 4  # keep every slice 16-byte aligned
-        self.flat = torch.zeros(total, device=device, dtype=dtype)
-        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(params, self.offsets)]
-        self.expected = len(params)
+    def __init__(self, arena, first, last):
+        """parameters arena.params[first:last] -> flat[lo:hi]"""
+        self.first, self.last = first, last
+        self.lo = arena.offsets[first]
+        self.hi = arena.offsets[last - 1] + (arena.params[last - 1].numel() + 3) // 4 * 4
+        self.flat = arena.flat[self.lo:self.hi]
+        self.expected = None     # set of parameter indices that received a gradient in the previous pass
         self.reset()
 
     def reset(self):
         self.ready = set()
-        self.streams = {}    # raw stream handle -> stream on which some gradient of this bucket was produced
+        self.streams = {}        # raw stream handle -> stream on which some gradient of this bucket was produced
         self.work = None
         self.launched = False
 
@@ -67,69 +72,84 @@ class DistributedDataParallel(nn.Module):
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 params.append(p)
-        self._buckets, cur, cur_elems = [], [], 0
-        for p in reversed(params):
-            cur.append(p)
-            cur_elems += p.numel()
-            if cur_elems >= self.bucket_elems:
-                self._buckets.append(_Bucket(cur, p.device, p.dtype))
-                cur, cur_elems = [], 0
-        if cur:
-            self._buckets.append(_Bucket(cur, cur[0].device, cur[0].dtype))
+        # gradient arena in reverse registration order; the buckets are consecutive runs of it
+        self.arena = GradArena(list(reversed(params)))
+        self._buckets, first, elems = [], 0, 0
+        for i, p in enumerate(self.arena.params):
+            elems += p.numel()
+            if elems >= self.bucket_elems:
+                self._buckets.append(_Bucket(self.arena, first, i + 1))
+                first, elems = i + 1, 0
+        if first < len(self.arena.params):
+            self._buckets.append(_Bucket(self.arena, first, len(self.arena.params)))
         self._where = {}
         for b in self._buckets:
-            for i, p in enumerate(b.params):
+            for i in range(b.first, b.last):
+                p = self.arena.params[i]
                 self._where[id(p)] = (b, i)
-                p.register_post_accumulate_grad_hook(self._make_hook(p))
-        self._callback_queued = False
-        self._never_used = None  # learnt on the first backward (ids of params without a gradient)
+                p.register_post_accumulate_grad_hook(self._hook)
+        self.arena.add_listener(self)
+        self._pass = None           # autograd graph-task id of the pass being tracked
+        self._finalized = True
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
     # ---- backward-time machinery -------------------------------------------------------------
-    def _make_hook(self, p):
-        def hook(param):
-            if not self._callback_queued:
-                self._callback_queued = True
-                for b in self._buckets:
-                    b.reset()
-                torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
-            b, i = self._where[id(param)]
-            b.ready.add(i)
-            if param.grad is not None and param.grad.is_cuda:
-                # the model runs its text / image streams on two HIP streams, so gradients of one bucket
-                # are produced on different streams: remember which (no event per gradient - a stream is
-                # in-order, so waiting for the stream at pack time covers every gradient enqueued on it)
-                st = torch.cuda.current_stream(param.grad.device)
-                b.streams.setdefault(st.cuda_stream, st)
-            if not self.delay_allreduce and self._never_used is not None and not b.launched \
-                    and len(b.ready) >= b.expected:
-                self._launch(b)
-        return hook
+    def _enter_pass(self):
+        """Called from the first gradient event of a backward pass (keyed on autograd's graph-task id, so an aborted
+        backward cannot leave the state half-way)."""
+        task = torch._C._current_graph_task_id()
+        if task != self._pass or self._finalized:
+            self._pass, self._finalized = task, False
+            for b in self._buckets:
+                b.reset()
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _hook(self, param):
+        self._enter_pass()
+        b, i = self._where[id(param)]
+        view = self.arena.views[i]
+        g = param.grad
+        if g is not None and g.data_ptr() != view.data_ptr():
+            # produced by a foreign autograd node: move it into the bucket (the native kernels write in place)
+            view.copy_(g)
+        if b.launched:
+            raise RuntimeError(
+                "DistributedDataParallel: parameter of shape %s received its gradient after its bucket had been "
+                "all-reduced - the set of used parameters changed between steps; construct with "
+                "delay_allreduce=True (the reference's multi-task mode, train_tasks.py:497)" % (tuple(param.shape),))
+        b.ready.add(i)
+        if g is not None and g.is_cuda:
+            # the model runs its text / image streams on two HIP streams, so gradients of one bucket
+            # are produced on different streams: remember which (no event per gradient - a stream is
+            # in-order, so waiting for the stream at launch time covers every gradient enqueued on it)
+            st = torch.cuda.current_stream(g.device)
+            b.streams.setdefault(st.cuda_stream, st)
+        if not self.delay_allreduce and b.expected is not None and b.ready == b.expected:
+            self._launch(b)
 
     def _launch(self, b):
-        """Pack the bucket (one multi-tensor copy; unused slices are zero) and start its all-reduce."""
+        """Start the in-place all-reduce of the bucket's arena range."""
         if b.streams:
             cur = torch.cuda.current_stream()
             for handle, st in b.streams.items():
                 if handle != cur.cuda_stream:
                     cur.wait_stream(st)
-        src, dst = [], []
-        for i, p in enumerate(b.params):
-            if p.grad is not None and p.grad.data_ptr() != b.views[i].data_ptr():
-                src.append(p.grad)
-                dst.append(b.views[i])
-            elif p.grad is None:
-                b.views[i].zero_()
-        if src:
-            torch._foreach_copy_(dst, src)
         op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
         b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
         b.launched = True
 
+    def arena_backward_done(self):
+        """Arena listener: the backward pass that wrote gradients is over (covers passes in which no
+        post-accumulate hook fired, e.g. pure accumulation into existing gradients)."""
+        if not self._finalized and self._pass is not None:
+            self._finalize()
+
     def _finalize(self):
-        self._callback_queued = False
+        if self._finalized:
+            return
+        self._finalized = True
         for b in self._buckets:  # whatever did not complete during backward (unused params, delayed mode)
             if not b.launched:
                 self._launch(b)
@@ -137,12 +157,8 @@ class DistributedDataParallel(nn.Module):
             b.work.wait()
             if not self._native_avg:
                 b.flat.div_(self.world_size)
-            for i, p in enumerate(b.params):
-                if i in b.ready:
-                    p.grad = b.views[i]
-        if self._never_used is None:
-            self._never_used = set()
-            for b in self._buckets:
-                unused = [i for i in range(len(b.params)) if i not in b.ready]
-                self._never_used.update(id(b.params[i]) for i in unused)
-                b.expected = len(b.params) - len(unused)
+            for i in b.ready:
+                p = self.arena.params[i]
+                if p.grad is None or p.grad.data_ptr() != self.arena.views[i].data_ptr():
+                    p.grad = self.arena.alias(i)
+            b.expected = set(b.ready)    # learnt / refreshed for the next pass

@@ -155,10 +155,12 @@ def linear_bwd_input(dy, weights, in_features, residual=None, mul=None):
     return dx
 
 
-def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
+def linear_bwd_weight(dy, x, nseg, seg_n, want_bias, dw_out=None, db_out=None):
     """Per segment: dW_s = dY[:, s]^T @ X and db_s = colsum(dY[:, s]) in one call.
-    Returns (list dW, list db-or-None). The split-K kernel adds into its targets with atomics: all of a
-    call's gradients are slices of ONE zero-filled buffer (one fill launch instead of two per segment)."""
+    Returns (list dW, list db-or-None). The split-K kernel ADDS into its targets with atomics. dw_out / db_out:
+    per-segment target tensors (gradient-arena slices: zero-filled once per backward pass, or holding an earlier
+    contribution) or None; the targets not given are slices of ONE zero-filled buffer allocated here (one fill
+    launch instead of two per segment)."""
     dy = _contig(dy)
     K = x.shape[-1]
     x2, ldx, _ = _row_view(x, K)
@@ -169,15 +171,25 @@ def linear_bwd_weight(dy, x, nseg, seg_n, want_bias):
     a.X, a.ldx = N.dev_f32(x2, "linear input"), ldx
     a.ldw, a.accumulate = K, 1
     wsz, bsz = (seg_n * K + 3) // 4 * 4, (seg_n + 3) // 4 * 4          # every slice stays 16-byte aligned
-    flat = torch.zeros(nseg * wsz + sum(bsz for s in range(nseg) if want_bias[s]), dtype=torch.float32,
-                       device=dy.device)
-    dws, dbs, off = [], [], nseg * wsz
+    dw_out = dw_out if dw_out is not None else [None] * nseg
+    db_out = db_out if db_out is not None else [None] * nseg
+    need = sum(wsz for s in range(nseg) if dw_out[s] is None) + \
+        sum(bsz for s in range(nseg) if want_bias[s] and db_out[s] is None)
+    flat = torch.zeros(need, dtype=torch.float32, device=dy.device) if need else None
+    dws, dbs, off = [], [], 0
     for s in range(nseg):
-        dw = flat[s * wsz:s * wsz + seg_n * K].view(seg_n, K)
+        dw = dw_out[s]
+        if dw is None:
+            dw = flat[off:off + seg_n * K].view(seg_n, K)
+            off += wsz
+        elif dw.shape != (seg_n, K) or not dw.is_contiguous():
+            raise RuntimeError("linear_bwd_weight: gradient target must be a contiguous [seg_n, K] tensor")
         db = None
         if want_bias[s]:
-            db = flat[off:off + seg_n]
-            off += bsz
+            db = db_out[s]
+            if db is None:
+                db = flat[off:off + seg_n]
+                off += bsz
         a.dW[s] = dw.data_ptr()
         a.dbias[s] = db.data_ptr() if db is not None else None
         dws.append(dw)
@@ -227,13 +239,14 @@ def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma):
-    """Returns (dx, dgamma, dbeta); x is the normalised input (the sum when the forward had x2)."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None):
+    """Returns (dx, dgamma, dbeta); x is the normalised input (the sum when the forward had x2). dgamma / dbeta:
+    optional [cols] targets (OVERWRITTEN - the column reduction is a deterministic two-stage sum)."""
     dy, x = _contig(dy), _contig(x)
     rows, cols = _rows(x)
     dx = torch.empty_like(x)
-    dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+    dgamma = dgamma if dgamma is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
+    dbeta = dbeta if dbeta is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
     ws = torch.empty(N.lib().vb_layernorm_bwd_workspace(rows, cols), dtype=torch.float32, device=x.device)
     N.check(N.lib().vb_layernorm_bwd(
         N.stream_ptr(), rows, cols, N.dev_f32(dy, "layernorm grad_output"), N.dev_f32(x, "layernorm input"),
@@ -272,16 +285,20 @@ def text_embed_ln_fwd(ids, seg, word, pos, typ, gamma, beta, eps, task_ids=None,
     return out, mean, rstd, presum
 
 
-def text_embed_bwd(dx, ids, seg, task_ids, word_shape, pos_shape, type_shape, task_shape):
-    """Scatter-add dx (gradient of the pre-LayerNorm sum) into fresh zero tables."""
+def text_embed_bwd(dx, ids, seg, task_ids, word_shape, pos_shape, type_shape, task_shape, out=None):
+    """Scatter-add dx (gradient of the pre-LayerNorm sum) into zero tables (fresh ones, or the accumulating targets
+    `out` = [dword, dpos, dtype, dtask] with None for the ones to allocate)."""
     dx = _contig(dx)
     ids, seg = _contig(ids), _contig(seg)
     B, T = ids.shape
     dev = dx.device
-    dword = torch.zeros(word_shape, dtype=torch.float32, device=dev)
-    dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dev)
-    dtype = torch.zeros(type_shape, dtype=torch.float32, device=dev)
-    dtask = torch.zeros(task_shape, dtype=torch.float32, device=dev) if task_ids is not None else None
+    out = out if out is not None else [None] * 4
+    dword = out[0] if out[0] is not None else torch.zeros(word_shape, dtype=torch.float32, device=dev)
+    dpos = out[1] if out[1] is not None else torch.zeros(pos_shape, dtype=torch.float32, device=dev)
+    dtype = out[2] if out[2] is not None else torch.zeros(type_shape, dtype=torch.float32, device=dev)
+    dtask = None
+    if task_ids is not None:
+        dtask = out[3] if out[3] is not None else torch.zeros(task_shape, dtype=torch.float32, device=dev)
     if task_ids is not None:
         task_ids = _contig(task_ids.view(-1))
     N.check(N.lib().vb_text_embed_bwd(

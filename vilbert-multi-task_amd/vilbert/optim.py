@@ -35,6 +35,23 @@ class AdamW(Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
         super(AdamW, self).__init__(params, defaults)
         self._plan_key, self._plan = None, None
+        self._arena = None
+        self._ensure_arena()
+
+    def _ensure_arena(self):
+        """Gives the optimizer's parameters a gradient arena (arena.py: gradients at fixed addresses in one flat
+        buffer, zero-filled once per backward, written in place by the backward kernels) unless something else - the
+        data-parallel wrapper - already manages them. Done at construction when the parameters are on the device,
+        else at the first step()."""
+        if self._arena is not None:
+            return
+        from . import arena
+        params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return
+        if all(arena.lookup(p) is not None for p in params):
+            return
+        self._arena = arena.GradArena(list(reversed(params)))
 
     def _build_plan(self, entries, device):
         """Static part of the launch tables for this set of tensors: chunk lists on the device and a
@@ -86,6 +103,7 @@ class AdamW(Optimizer):
                 entries.append((p, state, group))
         if not entries:
             return loss
+        self._ensure_arena()
         device = entries[0][0].device
         key = tuple((p.data_ptr(), st["exp_avg"].data_ptr()) for p, st, _ in entries)
         if key != self._plan_key:
