@@ -175,6 +175,8 @@ def main():
                          "pipeline (pinned double-buffered H2D + vb_concap_finish_batch): the PCIe-inclusive rate")
     ap.add_argument("--gemm-breakdown", action="store_true", help="print the per-shape GEMM time of the profiled step "
                     "(stderr; HIP events around every launch, single stream)")
+    ap.add_argument("--graph", action="store_true", help="(train) capture the whole step - forward, backward, gradient "
+                    "exchange, AdamW - into ONE HIP graph (vilbert/graphed.py) and time the replays")
     ap.add_argument("--global-batch", type=int, default=0, help="GLOBAL batch divided over the ranks (strong scaling; the "
                     "reference's own data-parallel mode, train_concap.py:290-294) instead of a fixed per-GPU batch")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the global512 / fwd_b512 legs of the default line")
@@ -232,7 +234,7 @@ def main():
 
     train_state = {}
 
-    def train_workload(batch):
+    def train_workload(batch, graph=False):
         """train_concap.py step (reference :523-585): BertForMultiModalPreTraining in train mode (dropout on), the
         loader's shapes (36 regions + 1 global-mean region row -> R = 37, 36 tokens, 36x1601 region targets), loss =
         masked-LM + masked-region KL + alignment, backward, gradient all-reduce (N > 1), AdamW step. The model /
@@ -263,13 +265,19 @@ def main():
             loss.backward()
             optim.step()
             return loss
+        if graph:
+            # one hipGraphLaunch per step: fixed-capacity label gather, device-side dropout counter, static tables
+            from vilbert.graphed import GraphedTrainStep
+            gs = GraphedTrainStep(net, optim, inp)
+            train_state.setdefault("graphs", []).append(gs)
+            return (lambda: gs(*inp)), xb, net
         return tstep, xb, net
 
     if args.mode == "fwd":
         step, x, model = forward_workload(B)
         n_reg = N_REG
     else:
-        step, x, model = train_workload(B)
+        step, x, model = train_workload(B, graph=args.graph)
         n_reg = N_REG + 1
         opt = train_state["opt"]
 
@@ -313,6 +321,22 @@ def main():
                               "divided over the ranks (reference train_concap.py:290-294)"}
         del gstep, gx
     if default_line and world == 1:
+        # the reference's per-GPU batch (512 / 8 GPUs = 64): eager (host-bound: ~2,600 launches per step) against the
+        # same step replayed as ONE HIP graph
+        e64, _, _ = train_workload(64)
+        n64 = max(6, args.steps)
+        e_dt = timed(e64, 2, n64)
+        g64, _, _ = train_workload(64, graph=True)
+        g_dt = timed(g64, 2, n64)
+        for gs in train_state.pop("graphs", []):
+            gs.check()
+            gs.close()
+        extra["b64_graph"] = {"eager": round(64 * n64 / e_dt, 2), "graphed": round(64 * n64 / g_dt, 2), "unit": "samples/s",
+                              "per_gpu_batch": 64, "steps": n64, "eager_ms_per_step": round(1e3 * e_dt / n64, 3),
+                              "graphed_ms_per_step": round(1e3 * g_dt / n64, 3),
+                              "note": "train_concap step at the reference's per-GPU batch 64: eager launches vs the "
+                                      "whole step (fwd + bwd + AdamW) replayed as one hipGraphLaunch (vilbert/graphed.py)"}
+        del e64, g64
         fstep, _, fmodel = forward_workload(512)
         n_f = max(5, args.steps // 2)
         f_dt = timed(fstep, 2, n_f)
@@ -329,7 +353,7 @@ def main():
     # The same workload with the opt-in bf16x6 GEMM mode (fp32 operands split into 3 bf16 planes, six MFMA
     # products per fp32 product; passes the same parity tests) - reported beside the primary number.
     alt = None
-    if args.gemm_mode == "f32" and world == 1 and not args.no_alt_mode:
+    if args.gemm_mode == "f32" and world == 1 and not args.no_alt_mode and not args.graph:
         _native.set_gemm_mode("bf16x6")
         for _ in range(2):
             step()
@@ -394,11 +418,14 @@ def main():
     # time a GEMM that shares the chip with the other stream's kernels, not the kernel itself.
     from vilbert import vilbert as _vb
     two = _vb.set_two_streams(False)
-    step()
+    pstep = step
+    if args.graph and args.mode == "train":
+        pstep = train_workload(B)[0]      # per-launch events need eager launches (same model, same optimizer)
+    pstep()
     torch.cuda.synchronize()
     ops.profile_linear(True)
     for _ in range(prof_steps):
-        step()
+        pstep()
     torch.cuda.synchronize()
     gemm_ms, gemm_flops, gemm_launches = ops.profile_linear(False)
     _vb.set_two_streams(two)
@@ -448,6 +475,7 @@ def main():
                                     "grad all-reduce + AdamW, %d regions + 1 global row" % N_REG, B, N_TOK, n_reg),
                        "per_gpu_batch": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world, "visible_gpus": torch.cuda.device_count(),
+                       "launch": "one HIP graph per step" if args.graph else "eager",
                        "gflop_per_sample_model": round(mult * total_f / 1e9, 3),
                        "gflop_per_sample_executed": round(mult * exec_f / 1e9, 3),
                        "gflop_per_sample_bertmodel": round(mult * bert_f / 1e9, 3)},

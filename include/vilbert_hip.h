@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 6
+#define VB_ABI_VERSION 7
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -56,6 +56,14 @@ const char* vb_error_string(int code);
  * unknown value only queries. Initial value from the environment variable VB_GEMM_MODE (f32 | bf16x6 |
  * bf16x3). */
 int vb_set_gemm_mode(int planes);
+
+/* Device-side step counter of the dropout masks. Every dropout mask is keep(seed, element index) with the seed given by
+ * the caller; when a counter is registered here each launch mixes *device_counter into its seed inside the kernel.
+ * A training step captured once into a HIP graph replays with constant host seeds: the graph contains one
+ * vb_bump_counter() node, so every replay draws fresh masks while forward and backward of one step still agree.
+ * device_counter: device pointer to one uint64 (NULL unregisters). The pointer must stay valid while registered. */
+int vb_set_seed_epoch(const uint64_t* device_counter);
+int vb_bump_counter(void* stream, uint64_t* device_counter);   /* *device_counter += 1 on the stream */
 
 /* Tile selection of the fp32 GEMM kernels. Aligned launches (16-byte pointers, K % 16 == 0, N % 4 == 0) run the
  * second-generation kernel (v_mfma_f32_16x16x4_f32, block tile 32 TM x 32 TN from the menu 64x64, 96x96, 96x128,
@@ -311,6 +319,8 @@ int vb_adamw_step(void* stream, int32_t n_chunks, const vb_adamw_tensor* table, 
  *   row_loss[r] = sum_j t_j (log t_j - (s_j - lse[r]))  (terms with t_j == 0 are 0),  tsum[r] = sum_j t_j;
  *   loss[0] = sum(row_loss) / divisor, loss[1] = divisor  (loss points to TWO floats).
  * vb_kl_bwd: dscores[r][j] = (exp(s_j - lse[r]) tsum[r] - t_j) * grad_loss[0] / divisor.
+ * divisor_dev (may be NULL): DEVICE scalar that replaces `divisor` - the row count of a fixed-capacity gather that
+ * the host never learns (sync-free / graph-captured training step); rows whose target is all zero contribute 0.
  * ------------------------------------------------------------------------------------------ */
 int vb_xent_fwd(void* stream, int64_t rows, int32_t n, const float* logits, int64_t ld, const int64_t* labels,
                 int64_t ignore_index, float* row_loss, float* lse, float* loss, float* count);
@@ -318,10 +328,11 @@ int vb_xent_bwd(void* stream, int64_t rows, int32_t n, const float* logits, int6
                 int64_t ignore_index, const float* lse, const float* grad_loss, const float* count,
                 float* dlogits, int64_t ldd);
 int vb_kl_fwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
-              int64_t ldt, float divisor, float* row_loss, float* lse, float* tsum, float* loss);
+              int64_t ldt, float divisor, float* row_loss, float* lse, float* tsum, float* loss,
+              const float* divisor_dev);
 int vb_kl_bwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
               int64_t ldt, const float* lse, const float* tsum, const float* grad_loss, float divisor,
-              float* dscores, int64_t ldd);
+              float* dscores, int64_t ldd, const float* divisor_dev);
 
 /* ------------------------------------------------------------------------------------------
  * vb_concap_finish_batch: device-side finishing of a Conceptual-Captions pre-training batch

@@ -41,3 +41,19 @@ def test_synthetic_batch_follows_the_loader_conventions():
     assert (x["image_loc"][:, 0] == torch.tensor([0.0, 0.0, 1.0, 1.0, 1.0])).all()
     y = bench.synthetic_batch(cfg, 4, 36, 37, 7, True)
     assert all(torch.equal(x[k], y[k]) for k in x)                      # seeded
+
+
+def test_bench_starts_its_own_ranks_when_not_under_a_launcher():
+    """`python bench.py --gpus 2` without RANK in the environment re-executes itself through torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1). Without GPUs every rank stops at its device check - which proves
+    that the ranks were started with the right environment."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
+    assert r.returncode != 0
+    text = r.stdout + r.stderr
+    assert "GPU(s) visible" in text, text[-2000:]

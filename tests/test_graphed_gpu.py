@@ -1,0 +1,139 @@
+"""Sync-free / HIP-graph-captured training step (vilbert/graphed.py): fixed-capacity label gather, device-side dropout
+step counter, static optimizer table. The replayed step must train exactly like the eager one."""
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NAMES = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+         "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
+
+
+def _model(cfg, sd):
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+    m.load_state_dict(sd)
+    return m.to(DEV).train()
+
+
+def _batches(cfg, n, batch=6):
+    return [[synth.make_inputs(cfg, batch, 9, 8, seed=40 + i, with_labels=True)[k].to(DEV) for k in NAMES] for i in range(n)]
+
+
+def test_static_capacity_losses_and_gradients_equal_the_exact_gather():
+    import vilbert.vilbert as V
+    cfg = synth.tiny_config()
+    sd = synth.make_state_dict(cfg, "pretraining")
+    args = _batches(cfg, 1)[0]
+    orig, V._drop_p = V._drop_p, (lambda m: 0.0)
+    try:
+        res = []
+        for cap in (None, 0.5, 1.0):
+            m = _model(cfg, sd)
+            m.label_capacity = cap
+            out = m(*args)
+            sum(l.sum() for l in out).backward()
+            if cap is not None:
+                m.check_label_capacity()
+            res.append(([l.item() for l in out], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+        for losses, grads in res[1:]:
+            assert losses == pytest.approx(res[0][0], rel=1e-5)
+            assert grads.keys() == res[0][1].keys()
+            gmax = max(g.abs().max().item() for g in grads.values())
+            for n, g in grads.items():
+                assert (g - res[0][1][n]).abs().max().item() <= 2e-5 * g.abs().max().item() + 1e-6 * gmax, n
+        # an overflowing capacity is detected (off the hot path)
+        m = _model(cfg, sd)
+        m.label_capacity = 1e-9            # -> the 128-row minimum, still enough here; force a tiny one instead
+        V_cap, V._capacity = V._capacity, (lambda positions, frac: 2)
+        try:
+            m(*args)
+            with pytest.raises(RuntimeError, match="capacity"):
+                m.check_label_capacity()
+        finally:
+            V._capacity = V_cap
+    finally:
+        V._drop_p = orig
+
+
+def test_seed_epoch_changes_masks_and_keeps_forward_backward_consistent():
+    from vilbert import _native as N, ops
+    x = torch.ones(512, 257, device=DEV)
+    ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+    base = ops.dropout(x, 0.3, 99)
+    N.check(N.lib().vb_set_seed_epoch(ctr.data_ptr()), "set")
+    try:
+        assert torch.equal(ops.dropout(x, 0.3, 99), base)                  # counter 0: the host seed alone
+        N.check(N.lib().vb_bump_counter(N.stream_ptr(), ctr.data_ptr()), "bump")
+        y1 = ops.dropout(x, 0.3, 99)
+        assert not torch.equal(y1, base) and torch.equal(ops.dropout(x, 0.3, 99), y1)
+        # the GEMM epilogue and the attention kernels mix the same counter: fused == two-step, fwd probs == bwd mask
+        M, Nn, K = 192, 256, 64
+        a, w, r = torch.randn(M, K, device=DEV), torch.randn(Nn, K, device=DEV) * 0.1, torch.randn(M, Nn, device=DEV)
+        fused, _ = ops.linear_fwd(a, [w], [None], residual=r, drop_p=0.25, seed=7)
+        plain, _ = ops.linear_fwd(a, [w], [None])
+        assert torch.allclose(fused, ops.dropout(plain, 0.25, 7, r), rtol=1e-6, atol=1e-6)
+        N.check(N.lib().vb_bump_counter(N.stream_ptr(), ctr.data_ptr()), "bump")
+        assert not torch.equal(ops.linear_fwd(a, [w], [None], residual=r, drop_p=0.25, seed=7)[0], fused)
+    finally:
+        N.check(N.lib().vb_set_seed_epoch(None), "unset")
+    assert int(ctr.item()) == 2
+
+
+def test_graphed_step_trains_like_the_eager_step():
+    import vilbert.vilbert as V
+    from vilbert.graphed import GraphedTrainStep
+    from vilbert.optim import AdamW, WarmupLinearSchedule
+    cfg = synth.tiny_config()
+    sd = synth.make_state_dict(cfg, "pretraining")
+    data = _batches(cfg, 5)
+    orig, V._drop_p = V._drop_p, (lambda m: 0.0)
+    try:
+        # eager reference: one step per batch, linear warm-up / decay schedule stepped after every optimizer step
+        m0 = _model(cfg, sd)
+        o0 = AdamW(m0.parameters(), lr=1e-3, weight_decay=0.01)
+        s0 = WarmupLinearSchedule(o0, warmup_steps=2, t_total=20)
+        ref_losses = []
+        for args in data:
+            o0.zero_grad()
+            loss = sum(l.mean() for l in m0(*args))
+            loss.backward()
+            o0.step()
+            s0.step()
+            ref_losses.append(loss.item())
+
+        # graphed: construction (warm-up + capture on the first batch) must not train; then one replay per batch
+        m1 = _model(cfg, sd)
+        o1 = AdamW(m1.parameters(), lr=1e-3, weight_decay=0.01)
+        s1 = WarmupLinearSchedule(o1, warmup_steps=2, t_total=20)
+        step = GraphedTrainStep(m1, o1, data[0], warmup=3)
+        for (n, p), (_, q) in zip(_model(cfg, sd).named_parameters(), m1.named_parameters()):
+            assert torch.equal(p, q), "construction changed " + n
+        got = []
+        for args in data:
+            got.append(step(*args).item())
+            s1.step()
+            step.check()
+        step.close()
+        assert got == pytest.approx(ref_losses, rel=2e-4), (got, ref_losses)
+        for (n, p), (_, q) in zip(m0.named_parameters(), m1.named_parameters()):
+            assert torch.allclose(p, q, rtol=2e-3, atol=2e-5), n
+        assert step.replays == 5
+    finally:
+        V._drop_p = orig
+
+
+def test_graphed_step_draws_fresh_dropout_masks_every_replay():
+    from vilbert.graphed import GraphedTrainStep
+    from vilbert.optim import AdamW
+    cfg = synth.tiny_config()
+    sd = synth.make_state_dict(cfg, "pretraining")
+    args = _batches(cfg, 1)[0]
+    m = _model(cfg, sd)
+    opt = AdamW(m.parameters(), lr=0.0)        # frozen weights: the loss changes only through the dropout masks
+    step = GraphedTrainStep(m, opt, args, warmup=2)
+    losses = [step(*args).item() for _ in range(4)]
+    step.close()
+    assert all(l == l for l in losses) and len(set(losses)) == 4

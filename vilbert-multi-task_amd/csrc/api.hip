@@ -1,6 +1,16 @@
 // ABI version and error strings of libvilbert_hip.so.
 #include "common.h"
 
+namespace {
+const uint64_t* g_seed_epoch = nullptr;
+}
+const uint64_t* vb_seed_epoch() { return g_seed_epoch; }
+
+extern "C" int vb_set_seed_epoch(const uint64_t* device_counter) {
+    g_seed_epoch = device_counter;
+    return 0;
+}
+
 extern "C" int vb_abi_version(void) { return VB_ABI_VERSION; }
 
 extern "C" const char* vb_error_string(int code) {

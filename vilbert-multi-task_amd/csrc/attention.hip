@@ -44,6 +44,7 @@ struct AttnP {
     float scale;
     float drop_p, drop_scale;
     uint64_t seed;
+    const uint64_t* epoch;   // device step counter mixed into the seed (vb_set_seed_epoch), may be null
     long total;       // wave items
     // backward only
     const float* dO; long lddo;
@@ -81,7 +82,9 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // BWD = false: forward.  BWD = true: backward pass 1 (dQ and the D vector).
 template <int D, int NT, bool BWD>
-__global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
+    AttnP p = p_in;
+    p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= p.total) return;
@@ -246,7 +249,9 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p) {
 
 // Backward pass 2: one wave per (sample, head, 16-key tile); dK and dV.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
+    AttnP p = p_in;
+    p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= p.total) return;
@@ -370,7 +375,9 @@ __device__ __forceinline__ void load_frag_lds(f32x4 (&f)[DS], const float* s) {
 }
 
 template <int D, bool BWD>
-__global__ __launch_bounds__(256) void attn_q_lds_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_q_lds_kernel(const AttnP p_in) {
+    AttnP p = p_in;
+    p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
     extern __shared__ __attribute__((aligned(16))) float smem_att[];
     constexpr int LD = D + 4, DS = D / 16, NT = LDS_MAX_ROWS / 16;
     float* sK = smem_att;
@@ -526,7 +533,9 @@ __global__ __launch_bounds__(256) void attn_q_lds_kernel(const AttnP p) {
 
 // Backward pass 2, short sequences: Q and dO of the (sample, head) staged in LDS, one wave per 16 keys.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) {
+    AttnP p = p_in;
+    p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
     extern __shared__ __attribute__((aligned(16))) float smem_att[];
     constexpr int LD = D + 4, DS = D / 16;
     float* sQ = smem_att;
@@ -676,6 +685,7 @@ int fill_common(AttnP& p, const vb_attention_args* a) {
     p.Q = a->Q; p.ldq = a->ldq; p.K = a->K; p.ldk = a->ldk; p.V = a->V; p.ldv = a->ldv;
     p.mask = a->mask_add; p.scale = a->scale; p.lse = a->lse;
     p.drop_p = a->dropout_p; p.drop_scale = 1.0f / (1.0f - a->dropout_p); p.seed = a->seed;
+    p.epoch = a->dropout_p > 0.f ? vb_seed_epoch() : nullptr;
     return 0;
 }
 

@@ -14,6 +14,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// device pointer registered with vb_set_seed_epoch (or null): every dropout launch passes it to its kernel
+const uint64_t* vb_seed_epoch();
+
 static inline bool vb_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long n4, const f32x4* __re
 
 __global__ __launch_bounds__(256) void dropout_kernel(long n, const float* __restrict__ x,
                                                       const float* __restrict__ res, float* __restrict__ y,
-                                                      float p, float scale, uint64_t seed) {
+                                                      float p, float scale, uint64_t seed_in,
+                                                      const uint64_t* __restrict__ epoch) {
+    const uint64_t seed = vb_seed_with_epoch(seed_in, epoch);
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
@@ -70,7 +72,18 @@ extern "C" int vb_dropout(void* stream, int64_t n, const float* x, const float* 
     if (!vb_aligned16(x) || !vb_aligned16(y) || (residual != nullptr && !vb_aligned16(residual))) return VB_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, (long)n, x, residual, y, p,
-                       1.0f / (1.0f - p), seed);
+                       1.0f / (1.0f - p), seed, vb_seed_epoch());
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+namespace {
+__global__ void bump_counter_kernel(uint64_t* c) { *c += 1; }
+}  // namespace
+
+extern "C" int vb_bump_counter(void* stream, uint64_t* device_counter) {
+    if (device_counter == nullptr) return VB_E_BADARG;
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), device_counter);
     VB_LAUNCH_CHECK();
     return 0;
 }

@@ -496,6 +496,7 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
     if (a->dropout_p > 0.f && a->ldc != p.N) return VB_E_ALIGN;
     p.drop_p = a->dropout_p; p.drop_scale = 1.0f / (1.0f - a->dropout_p); p.seed = a->seed;
+    p.epoch = a->dropout_p > 0.f ? vb_seed_epoch() : nullptr;
     if (a->dropout_p > 0.f)
         p.epi = (a->act == VB_ACT_NONE && a->preact == nullptr && a->residual != nullptr) ? EPI_RES_DROP : EPI_GENERIC;
     else if (a->act == VB_ACT_NONE && a->preact == nullptr) p.epi = a->residual != nullptr ? EPI_RES : EPI_STORE;

@@ -38,6 +38,7 @@ struct GemmP {
     int flags;            // tuning knobs (VB_GEMM_FLAGS): 1 = raise wave priority around the MFMA block
     float drop_p, drop_scale;  // dropout on the activated value, before the residual (0 = off)
     uint64_t seed;
+    const uint64_t* epoch;     // device step counter mixed into the seed (vb_set_seed_epoch), may be null
     unsigned long long* dbg;   // lab only (vblab_gemm_cycles): block 0 stores its shader-clock span here
 };
 
@@ -56,6 +57,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict_
     const float* __restrict__ rbase =
         (MODE == EPI_RES || MODE == EPI_RES_DROP) ? p.R + (long)row0 * p.ldr + col0 : nullptr;
     float* __restrict__ pbase = MODE == EPI_PRE_GELU ? p.P + (long)row0 * p.ldp + col0 : nullptr;
+    const uint64_t seed = MODE == EPI_RES_DROP ? vb_seed_with_epoch(p.seed, p.epoch) : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -69,7 +71,7 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict_
                 if (MODE == EPI_GELU || MODE == EPI_PRE_GELU) v = gelu_erf(v);
                 if (MODE == EPI_RES_DROP) {
                     const uint64_t idx = (uint64_t)((long)(row0 + dr) * p.N + col0 + j * 32);
-                    v = vb_keep(p.seed, idx, p.drop_p) ? v * p.drop_scale : 0.f;
+                    v = vb_keep(seed, idx, p.drop_p) ? v * p.drop_scale : 0.f;
                 }
                 if (MODE == EPI_RES || MODE == EPI_RES_DROP) v += rbase[(long)dr * p.ldr + j * 32];
                 if (MODE == EPI_ATOMIC) unsafeAtomicAdd(c, v);
@@ -127,6 +129,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
         return;
     }
     const bool split = gridDim.y > 1;
+    const uint64_t seed = p.drop_p > 0.f ? vb_seed_with_epoch(p.seed, p.epoch) : 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + j * 32;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
                 if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
                 if (p.act == VB_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
-                if (p.drop_p > 0.f) v = vb_keep(p.seed, (uint64_t)((long)row * p.N + col), p.drop_p) ? v * p.drop_scale : 0.f;
+                if (p.drop_p > 0.f) v = vb_keep(seed, (uint64_t)((long)row * p.N + col), p.drop_p) ? v * p.drop_scale : 0.f;
                 if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
                 float* c = cptr + (long)dr * p.ldc + j * 32;
                 if (split) unsafeAtomicAdd(c, v);

@@ -60,8 +60,8 @@ __device__ __forceinline__ int v2_swz(int row) { return (-(row >> 2)) & 3; }
 template <int MODE, int TM, int TN, bool BIAS_SEG>
 __device__ __forceinline__ void epilogue_v2(const GemmP& p, float* __restrict__ cbase, const f32x4 (&acc)[TM][TN],
                                             int row0, int col0, bool lead, bool full) {
-    // row0 / col0: this lane's first row / column (global indices); cbase = C segment base (row 0 of the segment
-    // = global row row_seg0)
+    // row0 / col0: this lane's first row / column (global indices); cbase + row * ldc addresses global row `row`
+    const uint64_t seed = MODE == EPI_RES_DROP ? vb_seed_with_epoch(p.seed, p.epoch) : 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + j * 16;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void epilogue_v2(const GemmP& p, float* __restrict__ 
             if (MODE == EPI_RES_DROP) {
                 const uint64_t idx = (uint64_t)((long)row * p.N + col);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = vb_keep(p.seed, idx + e, p.drop_p) ? v[e] * p.drop_scale : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = vb_keep(seed, idx + e, p.drop_p) ? v[e] * p.drop_scale : 0.f;
             }
             if (MODE == EPI_RES || MODE == EPI_RES_DROP) {
                 if (lead) v += *reinterpret_cast<const f32x4*>(p.R + (long)row * p.ldr + col);

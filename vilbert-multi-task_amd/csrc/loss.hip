@@ -62,7 +62,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void xent_fwd_kernel(int n, const flo
 // loss = sum(row_loss) / count, count = number of rows with label != ignore (xent) or `divisor` (KL)
 __global__ __launch_bounds__(LOSS_THREADS) void loss_mean_kernel(long rows, const float* __restrict__ row_loss,
                                                                  const int64_t* __restrict__ labels, int64_t ignore,
-                                                                 float divisor, float* __restrict__ loss,
+                                                                 float divisor, const float* __restrict__ divisor_dev,
+                                                                 float* __restrict__ loss,
                                                                  float* __restrict__ count_out) {
     __shared__ float scratch[LOSS_THREADS / 64];
     float s = 0.f, c = 0.f;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_mean_kernel(long rows, cons
         if (labels != nullptr) c += labels[r] != ignore ? 1.f : 0.f;
     }
     s = block_reduce(s, false, scratch);
-    c = labels != nullptr ? block_reduce(c, false, scratch) : divisor;
+    c = labels != nullptr ? block_reduce(c, false, scratch) : (divisor_dev != nullptr ? divisor_dev[0] : divisor);
     if (threadIdx.x == 0) {
         loss[0] = s / c;                   // 0 / 0 = NaN when nothing is labelled, like the reference
         count_out[0] = c;
@@ -124,12 +125,13 @@ __global__ __launch_bounds__(LOSS_THREADS) void kl_bwd_kernel(int n, const float
                                                               const float* __restrict__ target, long ldt,
                                                               const float* __restrict__ lse, const float* __restrict__ tsum,
                                                               const float* __restrict__ gout, float divisor,
+                                                              const float* __restrict__ divisor_dev,
                                                               float* __restrict__ dscores, long ldd) {
     const long r = blockIdx.x;
     const float* x = scores + r * ld;
     const float* t = target + r * ldt;
     float* d = dscores + r * ldd;
-    const float l = lse[r], ts = tsum[r], g = gout[0] / divisor;
+    const float l = lse[r], ts = tsum[r], g = gout[0] / (divisor_dev != nullptr ? divisor_dev[0] : divisor);
     // d/dx_j of -sum_k t_k (x_k - lse) = softmax_j * sum(t) - t_j
     for (int j = threadIdx.x; j < n; j += LOSS_THREADS) d[j] = (expf(x[j] - l) * ts - t[j]) * g;
 }
@@ -148,7 +150,7 @@ extern "C" int vb_xent_fwd(void* stream, int64_t rows, int32_t n, const float* l
         VB_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, rows, row_loss, labels, ignore_index, 0.f,
-                       loss, count);
+                       (const float*)nullptr, loss, count);
     VB_LAUNCH_CHECK();
     return 0;
 }
@@ -166,7 +168,8 @@ extern "C" int vb_xent_bwd(void* stream, int64_t rows, int32_t n, const float* l
 }
 
 extern "C" int vb_kl_fwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
-                         int64_t ldt, float divisor, float* row_loss, float* lse, float* tsum, float* loss) {
+                         int64_t ldt, float divisor, float* row_loss, float* lse, float* tsum, float* loss,
+                         const float* divisor_dev) {
     if (rows < 0 || n <= 0 || ld < n || ldt < n) return VB_E_BADARG;
     if (!scores || !target || !row_loss || !lse || !tsum || !loss) return VB_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -177,19 +180,19 @@ extern "C" int vb_kl_fwd(void* stream, int64_t rows, int32_t n, const float* sco
     }
     // loss points to TWO floats: {sum(row_loss) / divisor, divisor}
     hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, rows, row_loss, (const int64_t*)nullptr,
-                       (int64_t)0, divisor, loss, loss + 1);
+                       (int64_t)0, divisor, divisor_dev, loss, loss + 1);
     VB_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int vb_kl_bwd(void* stream, int64_t rows, int32_t n, const float* scores, int64_t ld, const float* target,
                          int64_t ldt, const float* lse, const float* tsum, const float* grad_loss, float divisor,
-                         float* dscores, int64_t ldd) {
+                         float* dscores, int64_t ldd, const float* divisor_dev) {
     if (rows < 0 || n <= 0 || ld < n || ldt < n || ldd < n) return VB_E_BADARG;
     if (!scores || !target || !lse || !tsum || !grad_loss || !dscores) return VB_E_BADARG;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)rows), dim3(LOSS_THREADS), 0, (hipStream_t)stream, n, scores, ld,
-                       target, ldt, lse, tsum, grad_loss, divisor, dscores, ldd);
+                       target, ldt, lse, tsum, grad_loss, divisor, divisor_dev, dscores, ldd);
     VB_LAUNCH_CHECK();
     return 0;
 }

@@ -125,6 +125,8 @@ SIGNATURES = {
     "vb_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "vb_set_gemm_mode": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_gemm_tile": (ctypes.c_int, [ctypes.c_int]),
+    "vb_set_seed_epoch": (ctypes.c_int, [_P]),
+    "vb_bump_counter": (ctypes.c_int, [_P, _P]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
     "vb_linear_bwd_input": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdInputArgs)]),
     "vb_linear_bwd_weight": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdWeightArgs)]),
@@ -143,8 +145,8 @@ SIGNATURES = {
     "vb_adamw_step": (ctypes.c_int, [_P, _I32, _P, _P, _P, _I32]),
     "vb_xent_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "vb_xent_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64]),
-    "vb_kl_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _F32, _P, _P, _P, _P]),
-    "vb_kl_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _I64]),
+    "vb_kl_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _F32, _P, _P, _P, _P, _P]),
+    "vb_kl_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _I64, _P]),
     "vb_concap_finish_batch": (ctypes.c_int, [_P, ctypes.POINTER(ConcapBatch)]),
 }
 
@@ -163,7 +165,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 6:
+        if handle.vb_abi_version() != 7:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -1,0 +1,117 @@
+"""Whole training step as ONE HIP graph launch.
+
+At the reference's own per-GPU batch (global 512 over 8 GPUs = 64 samples, reference train_concap.py:290-294) the
+eager step is bound by the host: ~2,600 kernel launches + autograd bookkeeping per step against ~30 ms of GPU work.
+Everything in the native layer only enqueues on the current stream and never allocates or synchronises behind torch's
+back, so forward + backward + optimizer can be captured once and replayed with a single ``hipGraphLaunch``:
+
+  * the labelled rows are gathered into fixed-capacity buffers (``model.label_capacity``, torch.nonzero_static) - no
+    host sync, static shapes;
+  * the gradients live at fixed addresses (arena.py) and ``param.grad`` never changes identity, so the optimizer's
+    pointer table is static; only its per-step scalars (learning-rate schedule, bias correction) are rewritten by the
+    host into the pinned buffer a captured copy node reads (AdamW.prepare_replay);
+  * the dropout masks are functions of (seed, element index): the host seeds are frozen into the graph, the graph's first
+    node increments a DEVICE step counter that every dropout kernel mixes into its seed (vb_set_seed_epoch), so each
+    replay draws fresh masks and forward / backward of a step still agree.
+
+Usage (same arguments as ``model(*inputs)``; ``loss_fn`` maps the model's outputs to the scalar that is
+back-propagated, default = sum of the means of the three pre-training losses as in train_concap.py:555-566)::
+
+    step = GraphedTrainStep(model, optimizer, example_inputs)
+    for batch in loader:
+        loss = step(*batch)          # copies the batch into the static inputs, replays the graph
+"""
+import torch
+
+from . import _native as N
+
+
+def _default_loss(outputs):
+    return sum(o.mean() for o in outputs[:3])
+
+
+class GraphedTrainStep(object):
+    def __init__(self, model, optimizer, example_inputs, loss_fn=None, label_capacity=0.25, warmup=3):
+        self.model, self.opt = model, optimizer
+        self.loss_fn = loss_fn or _default_loss
+        base = model.module if hasattr(model, "module") else model
+        if hasattr(base, "label_capacity"):
+            base.label_capacity = label_capacity
+        self._base = base
+        dev = example_inputs[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedTrainStep needs HIP-device inputs - no CPU fallback")
+        self.static = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
+        # device step counter of the dropout masks
+        self.epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+        N.check(N.lib().vb_set_seed_epoch(self.epoch.data_ptr()), "vb_set_seed_epoch")
+        # Warm-up and capture must not train: parameters and optimizer state are snapshotted here and restored after
+        # the capture (the warm-up steps are real eager steps on the example batch; the capture itself executes nothing
+        # on the device but advances the host-side step counts).
+        snap_p = [p.detach().clone() for g in optimizer.param_groups for p in g["params"]]
+        snap_s = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()}
+                  for g in optimizer.param_groups for p in g["params"] if p in optimizer.state}
+        # eager warm-up on a side stream (allocator pools, optimizer state, gradient arena, GEMM plans) - the
+        # documented pattern for capturing a whole network
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager_step()
+        with torch.no_grad():
+            i = 0
+            for g in optimizer.param_groups:
+                for p in g["params"]:
+                    p.copy_(snap_p[i])
+                    i += 1
+                    st = optimizer.state.get(p)
+                    if st is None:
+                        continue
+                    old = snap_s.get(id(p))
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(old[k]) if old is not None else v.zero_()      # same tensors: the graph holds their addresses
+                        else:
+                            st[k] = old[k] if old is not None else 0
+            self.epoch.zero_()
+        del snap_p, snap_s
+        self.replays = 0
+
+    def _eager_step(self):
+        N.check(N.lib().vb_bump_counter(N.stream_ptr(), self.epoch.data_ptr()), "vb_bump_counter")
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.model(*self.static))
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def __call__(self, *inputs):
+        if len(inputs) != len(self.static):
+            raise RuntimeError("GraphedTrainStep: expected %d inputs" % len(self.static))
+        # the previous replay must be done with the optimizer's pinned table before the host rewrites it
+        torch.cuda.current_stream().synchronize()
+        for s, t in zip(self.static, inputs):
+            if torch.is_tensor(s) and s.data_ptr() != t.data_ptr():
+                if s.shape != t.shape or s.dtype != t.dtype:
+                    raise RuntimeError("GraphedTrainStep: input shape / dtype differs from the captured one")
+                s.copy_(t, non_blocking=True)
+        self.opt.prepare_replay()
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
+
+    def check(self):
+        """Off the hot path: raises if the fixed-capacity label gather of the last step overflowed."""
+        if hasattr(self._base, "check_label_capacity"):
+            self._base.check_label_capacity()
+
+    def close(self):
+        N.check(N.lib().vb_set_seed_epoch(None), "vb_set_seed_epoch")
+        if hasattr(self._base, "label_capacity"):
+            self._base.label_capacity = None

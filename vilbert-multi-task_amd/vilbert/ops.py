@@ -432,9 +432,17 @@ def xent_bwd(grad_loss, logits, labels, ignore_index, lse, count):
     return d
 
 
+def _divisor(divisor):
+    """(host float, device pointer or None) of a KL divisor given as a number or as a 1-element device tensor."""
+    if torch.is_tensor(divisor):
+        d = _contig(divisor.reshape(1))
+        return 0.0, N.dev_f32(d, "kl_div divisor"), d
+    return float(divisor), None, None
+
+
 def kl_fwd(scores, target, divisor):
-    """sum(KLDiv(log_softmax(scores, 1), target)) / divisor; scores / target [rows, n] fp32.
-    Returns (loss 0-dim, lse [rows], tsum [rows])."""
+    """sum(KLDiv(log_softmax(scores, 1), target)) / divisor; scores / target [rows, n] fp32; divisor: a number or
+    a 1-element fp32 DEVICE tensor (no host sync). Returns (loss 0-dim, lse [rows], tsum [rows])."""
     if scores.dim() != 2 or scores.shape != target.shape:
         raise RuntimeError("kl_div: expected scores and target of the same [rows, n] shape")
     scores, target = _contig(scores), _contig(target)
@@ -444,9 +452,10 @@ def kl_fwd(scores, target, divisor):
     lse = torch.empty(rows, dtype=torch.float32, device=dev)
     tsum = torch.empty(rows, dtype=torch.float32, device=dev)
     out = torch.empty(2, dtype=torch.float32, device=dev)
+    dh, dd, _keep = _divisor(divisor)
     N.check(N.lib().vb_kl_fwd(N.stream_ptr(), rows, n, N.dev_f32(scores, "kl_div scores"), n,
-                              N.dev_f32(target, "kl_div target"), n, float(divisor), row_loss.data_ptr(),
-                              lse.data_ptr(), tsum.data_ptr(), out.data_ptr()), "vb_kl_fwd")
+                              N.dev_f32(target, "kl_div target"), n, dh, row_loss.data_ptr(),
+                              lse.data_ptr(), tsum.data_ptr(), out.data_ptr(), dd), "vb_kl_fwd")
     return out[0], lse, tsum
 
 
@@ -455,8 +464,9 @@ def kl_bwd(grad_loss, scores, target, lse, tsum, divisor):
     rows, n = scores.shape
     grad_loss = _contig(grad_loss).reshape(1)
     d = torch.empty_like(scores)
+    dh, dd, _keep = _divisor(divisor)
     N.check(N.lib().vb_kl_bwd(N.stream_ptr(), rows, n, N.dev_f32(scores, "kl_div scores"), n,
                               N.dev_f32(target, "kl_div target"), n, N.dev_f32(lse, "kl_div lse"),
-                              N.dev_f32(tsum, "kl_div tsum"), N.dev_f32(grad_loss, "kl_div grad"), float(divisor),
-                              d.data_ptr(), n), "vb_kl_bwd")
+                              N.dev_f32(tsum, "kl_div tsum"), N.dev_f32(grad_loss, "kl_div grad"), dh,
+                              d.data_ptr(), n, dd), "vb_kl_bwd")
     return d

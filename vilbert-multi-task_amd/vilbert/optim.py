@@ -109,33 +109,68 @@ class AdamW(Optimizer):
         if key != self._plan_key:
             self._plan_key, self._plan = key, self._build_plan(entries, device)
         plan = self._plan
-        tab = plan["tab"]
-        keep = []
-        for i, (p, st, g) in enumerate(entries):
-            grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            keep.append(grad)
-            b1, b2 = g["betas"]
-            step_size = g["lr"]
-            if g["correct_bias"]:
-                step_size = step_size * math.sqrt(1.0 - b2 ** st["step"]) / (1.0 - b1 ** st["step"])
-            tab["grad"][i] = grad.data_ptr()
-            tab["step_size"][i], tab["beta1"][i], tab["beta2"][i] = step_size, b1, b2
-            tab["eps"][i], tab["decay"][i] = g["eps"], g["lr"] * g["weight_decay"]
+        capturing = torch.cuda.is_current_stream_capturing()
+        keep = self._fill_table(plan, entries)
         # asynchronous upload through pinned memory: no host <-> device synchronisation in step()
-        k = plan["turn"]
-        plan["turn"] = k ^ 1
-        if plan["events"][k] is not None:
-            plan["events"][k].synchronize()
-        plan["pinned"][k].numpy()[:] = tab.view(np.uint8).reshape(-1)
+        if capturing:
+            # HIP-graph capture: the copy node reads pinned buffer 0 at every replay; prepare_replay() refreshes it
+            k = 0
+            self._captured = (plan, entries)
+        else:
+            k = plan["turn"]
+            plan["turn"] = k ^ 1
+            if plan["events"][k] is not None:
+                plan["events"][k].synchronize()
+        plan["pinned"][k].numpy()[:] = plan["tab"].view(np.uint8).reshape(-1)
         dev_tab = plan["dev_tab"]
         dev_tab.copy_(plan["pinned"][k], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        plan["events"][k] = ev
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+            plan["events"][k] = ev
         N.check(N.lib().vb_adamw_step(N.stream_ptr(), plan["n_chunks"], dev_tab.data_ptr(),
                                       plan["chunk_tensor"].data_ptr(), plan["chunk_off"].data_ptr(), CHUNK_ELEMS),
                 "vb_adamw_step")
+        del keep
         return loss
+
+    def _fill_table(self, plan, entries, pointers=True):
+        """Per-step columns of the launch table: gradient pointers and the hyper-parameters of this step (vectorised:
+        this runs on the host once per step, ~530 rows)."""
+        tab = plan["tab"]
+        keep = []
+        if pointers:
+            for i, (p, st, g) in enumerate(entries):
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep.append(grad)
+                tab["grad"][i] = grad.data_ptr()
+        n = len(entries)
+        gi = plan.get("group_index")
+        if gi is None or len(gi) != n:
+            ids = {id(g): k for k, g in enumerate(self.param_groups)}
+            gi = plan["group_index"] = np.array([ids[id(g)] for _p, _st, g in entries], dtype=np.int64)
+        groups = self.param_groups
+        lr = np.array([g["lr"] for g in groups], dtype=np.float64)[gi]
+        b1 = np.array([g["betas"][0] for g in groups], dtype=np.float64)[gi]
+        b2 = np.array([g["betas"][1] for g in groups], dtype=np.float64)[gi]
+        eps = np.array([g["eps"] for g in groups], dtype=np.float64)[gi]
+        wd = np.array([g["weight_decay"] for g in groups], dtype=np.float64)[gi]
+        corr = np.array([bool(g["correct_bias"]) for g in groups])[gi]
+        steps = np.fromiter((st["step"] for _p, st, _g in entries), dtype=np.float64, count=n)
+        step_size = np.where(corr, lr * np.sqrt(1.0 - b2 ** steps) / (1.0 - b1 ** steps), lr)
+        tab["step_size"], tab["beta1"], tab["beta2"] = step_size, b1, b2
+        tab["eps"], tab["decay"] = eps, lr * wd
+        return keep
+
+    def prepare_replay(self):
+        """Host side of one replay of a captured step (GraphedTrainStep): advances the step counts and rewrites the
+        pinned table the captured copy node reads (learning-rate schedule, bias correction). The previous replay
+        must have finished reading the table (the caller synchronises)."""
+        plan, entries = self._captured
+        for _p, st, _g in entries:
+            st["step"] += 1
+        self._fill_table(plan, entries, pointers=False)     # the gradients live at fixed addresses (arena)
+        plan["pinned"][0].numpy()[:] = plan["tab"].view(np.uint8).reshape(-1)
 
 
 class ConstantLRSchedule(LambdaLR):

@@ -90,6 +90,8 @@ class BertConfig(object):
 # replays every backward op on the stream its forward ran on, so the overlap carries over to backward.
 # VB_TWO_STREAMS=0 turns it off.
 _TWO_STREAMS = os.environ.get("VB_TWO_STREAMS", "1") != "0"
+# inside a HIP-graph capture the fork / join becomes two parallel branches of the graph (VB_GRAPH_STREAMS=0: one chain)
+_TWO_STREAMS_IN_GRAPH = os.environ.get("VB_GRAPH_STREAMS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -113,7 +115,7 @@ def _concurrent(side_fn, main_fn, side_inputs):
     side_inputs: tensors (allocated on the current stream) the side work reads. Falls back to sequential
     execution (side first) when two-stream mode is off, on CPU tensors, or while a graph is being captured."""
     t0 = side_inputs[0]
-    if not (_TWO_STREAMS and t0.is_cuda) or torch.cuda.is_current_stream_capturing():
+    if not (_TWO_STREAMS and t0.is_cuda) or (torch.cuda.is_current_stream_capturing() and not _TWO_STREAMS_IN_GRAPH):
         return side_fn(), main_fn()
     main = torch.cuda.current_stream(t0.device)
     side = _side_stream(t0.device)
@@ -724,6 +726,11 @@ class BertImagePredictionHead(nn.Module):
         return F.linear(self.transform(hidden_states), self.decoder.weight, self.decoder.bias)
 
 
+def _capacity(positions, frac):
+    """Fixed gather capacity: `frac` of the positions, a multiple of 32 (aligned wgrad contraction, whole MFMA tiles)."""
+    return max(32, min((positions + 31) // 32 * 32, (int(positions * frac) + 31) // 32 * 32))
+
+
 def _fuse_pooled(fusion_method, pooled_output_t, pooled_output_v):
     if fusion_method == "sum":
         return pooled_output_t + pooled_output_v
@@ -817,7 +824,8 @@ class BertModel(BertPreTrainedModel):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_txt)
         if image_attention_mask is None:
-            image_attention_mask = torch.ones(input_imgs.size(0), input_imgs.size(1)).type_as(input_txt)
+            image_attention_mask = torch.ones(input_imgs.size(0), input_imgs.size(1), dtype=input_txt.dtype,
+                                              device=input_txt.device)      # (created on the device: graph-capturable)
         if self.task_specific_tokens:
             # the mask grows at position 0 (:1331-1334) while the task embedding sits at position 1
             mask_tokens = input_txt.new().resize_(input_txt.size(0), 1).fill_(1)
@@ -829,8 +837,9 @@ class BertModel(BertPreTrainedModel):
         extended_attention_mask2 = attention_mask.unsqueeze(2).to(dtype=next(self.parameters()).dtype)
 
         if co_attention_mask is None:
-            co_attention_mask = torch.zeros(input_txt.size(0), input_imgs.size(1), input_txt.size(1)) \
-                .type_as(extended_image_attention_mask)
+            co_attention_mask = torch.zeros(input_txt.size(0), input_imgs.size(1), input_txt.size(1),
+                                            dtype=extended_image_attention_mask.dtype,
+                                            device=extended_image_attention_mask.device)
         # scaled by 5 and then never consumed, as in the reference (:1364-1375)
         extended_co_attention_mask = (co_attention_mask.unsqueeze(1) * 5.0).to(
             dtype=next(self.parameters()).dtype)
@@ -861,6 +870,10 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         self.apply(self.init_weights)
         self.visual_target = config.visual_target
         self.num_negative = config.num_negative
+        # None: the labelled rows are gathered exactly (one host sync per step); a fraction in (0, 1]: sync-free
+        # fixed-capacity gather of that share of the token / region positions (see _losses_at_labelled_positions)
+        self.label_capacity = None
+        self._label_counts = None
         self.loss_fct = CrossEntropyLoss(ignore_index=-1)
         print("model's visual target is ", config.visual_target)
         if self.visual_target == 0:
@@ -922,13 +935,38 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         caller then takes the reference-shaped path, which yields the reference's NaN)."""
         cls = self.cls
         lm_flat = masked_lm_labels.reshape(-1)
-        idx_t = torch.nonzero(lm_flat != -1).squeeze(1)
         labelled = image_label == 1
         n_reg_all = sequence_output_v.size(1)                       # regions incl. the global row 0
-        idx_r = torch.nonzero(labelled.reshape(-1)).squeeze(1)      # index into [B, n_reg_all - 1]
-        if idx_t.numel() == 0 or idx_r.numel() == 0:
-            return None
         per = n_reg_all - 1
+        static = (self.label_capacity is not None or torch.cuda.is_current_stream_capturing()) and self.visual_target == 0
+        if static:
+            # Sync-free variant (HIP-graph capture, small per-GPU batches): the labelled rows are gathered into
+            # FIXED-capacity buffers (torch.nonzero_static), the host never learns the counts. Padding rows carry
+            # label -1 / an all-zero target: they contribute nothing to the losses or to any gradient, and the
+            # divisors are device scalars. Counts above the capacity would silently drop rows, so they are recorded
+            # for check_label_capacity() (GraphedTrainStep polls it without stalling the device).
+            frac = self.label_capacity if self.label_capacity is not None else 0.25
+            cap_t = _capacity(lm_flat.numel(), frac)
+            cap_r = _capacity(labelled.numel(), frac)
+            mask_t = lm_flat != -1
+            idx_t = torch.nonzero_static(mask_t, size=cap_t, fill_value=0).squeeze(1)
+            n_t = mask_t.sum()
+            labels_t = torch.where(torch.arange(cap_t, device=idx_t.device) < n_t, lm_flat.index_select(0, idx_t),
+                                   torch.full_like(idx_t, -1))
+            mask_r = labelled.reshape(-1)
+            idx_r = torch.nonzero_static(mask_r, size=cap_r, fill_value=0).squeeze(1)
+            n_r = mask_r.sum()
+            valid_r = torch.arange(cap_r, device=idx_r.device) < n_r
+            self._label_counts = (n_t, n_r, cap_t, cap_r)
+            divisor_r = n_r.to(torch.float32).reshape(1)
+        else:
+            idx_t = torch.nonzero(lm_flat != -1).squeeze(1)
+            idx_r = torch.nonzero(labelled.reshape(-1)).squeeze(1)      # index into [B, n_reg_all - 1]
+            if idx_t.numel() == 0 or idx_r.numel() == 0:
+                return None
+            labels_t = lm_flat.index_select(0, idx_t)
+            valid_r = None
+            divisor_r = float(idx_r.numel())
         idx_v = idx_r + torch.div(idx_r, per, rounding_mode="floor") + 1   # same rows inside [B, n_reg_all]
 
         pooled_output = _dropout(_fuse_pooled(cls.fusion_method, pooled_output_t, pooled_output_v), cls.dropout)
@@ -939,18 +977,31 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
                                              ignore_index=-1)
 
         rows_t = sequence_output_t.reshape(-1, sequence_output_t.size(-1)).index_select(0, idx_t)
-        masked_lm_loss = F.cross_entropy(cls.predictions(rows_t), lm_flat.index_select(0, idx_t), ignore_index=-1)
+        masked_lm_loss = F.cross_entropy(cls.predictions(rows_t), labels_t, ignore_index=-1)
 
         rows_v = sequence_output_v.reshape(-1, sequence_output_v.size(-1)).index_select(0, idx_v)
         scores_v = cls.imagePredictions(rows_v)
         target = image_target.reshape(-1, image_target.size(-1)).index_select(0, idx_r)
+        if valid_r is not None:
+            target = target * valid_r.unsqueeze(1).to(target.dtype)     # padding rows: all-zero target
         if self.visual_target == 1:
             masked_img_loss = torch.sum(self.vis_criterion(scores_v, target)) / max(
                 torch.sum(labelled.unsqueeze(2).expand(-1, -1, image_target.size(-1))), 1)
         else:
             # divisor: the reference's max(sum(image_label == 1), 0) (:1520-1522) = the number of rows here
-            masked_img_loss = F.kl_div_log_softmax(scores_v, target, float(idx_r.numel()))
+            masked_img_loss = F.kl_div_log_softmax(scores_v, target, divisor_r)
         return masked_lm_loss.unsqueeze(0), masked_img_loss.unsqueeze(0), next_sentence_loss.unsqueeze(0)
+
+    def check_label_capacity(self):
+        """Raises if the last fixed-capacity label gather overflowed (synchronises; call it off the hot path)."""
+        if self._label_counts is None:
+            return
+        n_t, n_r, cap_t, cap_r = self._label_counts
+        n_t, n_r = int(n_t.item()), int(n_r.item())
+        if n_t > cap_t or n_r > cap_r:
+            raise RuntimeError("labelled rows exceed the fixed gather capacity (%d tokens / capacity %d, %d regions / "
+                               "capacity %d): raise model.label_capacity (fraction of positions, <= 1.0)"
+                               % (n_t, cap_t, n_r, cap_r))
 
     def _nce_region_loss(self, input_ids, prediction_scores_v, image_target, labelled):
         """visual_target == 2 (:1523-1575): 70 % negatives from other samples, 30 % from the same image."""
