@@ -52,9 +52,11 @@ const char* vb_error_string(int code);
 /* Arithmetic of every vb_linear_* GEMM: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products, the default),
  * 3 = "bf16x6": each fp32 operand split exactly into three bf16 planes and the six largest partial
  * products accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (fp32-class result, ~1.2x faster),
- * 2 = "bf16x3": two planes, three products (error ~2^-16 per product). Returns the previous mode; an
- * unknown value only queries. Initial value from the environment variable VB_GEMM_MODE (f32 | bf16x6 |
- * bf16x3). */
+ * 2 = "bf16x3": two planes, three products (error ~2^-16 per product), 1 = "bf16": operands rounded to bf16
+ * (round-to-nearest-even) on their way into LDS, ONE product per element on v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate, fp32 tensors in memory - the reduced-precision throughput mode (relative error ~2^-9 per operand:
+ * outside the 1e-4 parity bar, reported under its own tolerance). Returns the previous mode; an unknown value only
+ * queries. Initial value from the environment variable VB_GEMM_MODE (f32 | bf16x6 | bf16x3 | bf16). */
 int vb_set_gemm_mode(int planes);
 
 /* Device-side step counter of the dropout masks. Every dropout mask is keep(seed, element index) with the seed given by

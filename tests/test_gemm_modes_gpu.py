@@ -1,6 +1,10 @@
-"""The opt-in "split" GEMM modes (fp32 emulated on the bf16 matrix cores, csrc/gemm_split.hip) against the
-same fp64 references as the default exact-fp32 kernel, and model-level parity against the reference's
-golden vectors in bf16x6 mode (tolerance unchanged: fp32 1e-4)."""
+"""The opt-in GEMM modes on the bf16 matrix cores (csrc/gemm_planes.hip): "bf16x6" / "bf16x3" (fp32 emulated with 3 / 2
+bf16 planes per operand) against the same fp64 references as the default exact-fp32 kernel, model-level parity
+against the reference's golden vectors in bf16x6 mode (tolerance unchanged: fp32 1e-4), and the reduced-precision
+"bf16" mode (operands rounded to bf16, one product, fp32 accumulate) under ITS OWN stated tolerance: per GEMM
+|err| <= 2^-7 sqrt(K) max|a| max|b| (two operands rounded at 2^-9 relative each, errors adding in quadrature over K);
+at model level the measured output error against the real reference's golden vectors is asserted <= 3e-2 relative
+to each output's largest magnitude - it does NOT meet the 1e-4 bar and is never the default."""
 import pytest
 import torch
 
@@ -27,6 +31,8 @@ def _check(got, want64, mode):
     # bf16x6 keeps every partial product down to 2^-24: same tolerance as the fp32 kernel.
     # bf16x3 drops terms of relative size 2^-16 per product.
     tol = 3e-5 if mode == "bf16x6" else 6e-4
+    if mode == "bf16":
+        return _check_bf16(got, want64)
     got = got.detach().cpu().double()
     assert got.shape == want64.shape and torch.isfinite(got).all()
     scale = max(1.0, want64.abs().max().item())
@@ -34,7 +40,15 @@ def _check(got, want64, mode):
     assert err <= tol * scale, "max err %.3e (scale %.3e, mode %s)" % (err, scale, mode)
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"], indirect=True)
+def _check_bf16(got, want64):
+    got = got.detach().cpu().double()
+    assert got.shape == want64.shape and torch.isfinite(got).all()
+    err = (got - want64).abs().max().item()
+    assert err <= 2.0 ** -6 * max(1.0, want64.abs().max().item()), "bf16 mode: max err %.3e (scale %.3e)" % (
+        err, want64.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "bf16"], indirect=True)
 @pytest.mark.parametrize("M,N,K,nseg", [(128, 128, 16, 1), (300, 768, 768, 1), (180, 128, 192, 3), (100, 200, 52, 1),
                                         (77, 64, 36, 3), (73, 96, 5, 1), (1, 1, 4, 1), (640, 1024, 2048, 1)])
 def test_split_modes_forward_backward(mode, M, N, K, nseg):
@@ -72,3 +86,29 @@ def test_bf16x6_model_matches_reference_golden(mode, case):
     gold = helpers.load_golden(case)
     for i, n in enumerate(cases.output_names(case)):
         helpers.assert_close(cases.sample(case, n, out[i]), gold[n], "%s/%s [%s]" % (case, n, mode))
+
+
+@pytest.mark.parametrize("mode", ["bf16"], indirect=True)
+@pytest.mark.parametrize("case", ["base_2l2c_b8", "base_6l6c_b2"])
+def test_bf16_mode_model_error_is_reported_under_its_own_tolerance(mode, case):
+    """Reduced-precision mode against the REAL reference's outputs: it misses the 1e-4 bar (by design) and is bounded
+    by 3e-2 of each output's largest magnitude; the measured worst ratio is printed for DESIGN.md."""
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg, sd, x = cases.case_inputs(case)
+    m = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    m.load_state_dict(sd)
+    m = m.eval().to(DEV)
+    with torch.no_grad():
+        out = m(*helpers.to_device(cases.forward_args(case, x), DEV))
+    gold = helpers.load_golden(case)
+    worst = 0.0
+    for i, n in enumerate(cases.output_names(case)):
+        if n == "vision_logit":
+            continue          # carries the -10000 mask offsets
+        got = cases.sample(case, n, out[i]).cpu().double()
+        want = torch.as_tensor(gold[n]).double()
+        rel = ((got - want).abs().max() / want.abs().max()).item()
+        worst = max(worst, rel)
+        assert rel <= 3e-2, "%s/%s: bf16-mode error %.3e of the output range" % (case, n, rel)
+    print("bf16 mode, %s: worst output error %.2e of the output range (fp32 mode: < 1e-4)" % (case, worst))
+    assert worst > 1e-5       # it really is a different arithmetic

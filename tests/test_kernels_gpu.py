@@ -102,6 +102,45 @@ def test_linear_activation_derivative_and_multiplier_epilogues(ops, gemm_tile, c
     _close(dx, (dy.double() @ w.double()) * m.double(), 3e-5, 3e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(424, 1002, 256), (1628, 3054, 768)])
+def test_linear_padded_logits_path_ragged_contraction(ops, M, N, K):
+    """The MLM-decoder shape class: out-features N with N % 4 == 2 (30522), a row count that is no multiple of 16. The
+    logits live in a buffer whose row stride is rounded up to 4 floats (pad_cols); the backward GEMMs read the strided
+    gradient in place and split their contraction into an aligned bulk (second-generation kernel) + a <= 15-element
+    tail launch."""
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
+    y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()], pad_cols=True)
+    assert y.shape == (M, N) and y.stride() == ((N + 3) // 4 * 4, 1)
+    _close(y, x.double() @ w.double().t() + b.double())
+    dy_buf = torch.full((M, (N + 3) // 4 * 4), float("nan"))      # NaN in the pad columns: they must never be read
+    dy_buf[:, :N] = _rand(M, N, seed=4)
+    dy = dy_buf.cuda()[:, :N]
+    dx = ops.linear_bwd_input(dy, [w.cuda()], K)
+    _close(dx, dy_buf[:, :N].double() @ w.double(), 3e-5, 3e-5 * N / 256)
+    (dw,), (db,) = ops.linear_bwd_weight(dy, x.cuda(), 1, N, [True])
+    want = dy_buf[:, :N].double().t() @ x.double()
+    _close(dw, want, 3e-5, 3e-5 * max(1.0, want.abs().max().item()))
+    _close(db, dy_buf[:, :N].double().sum(0), 3e-5, 3e-5 * M / 64)
+
+
+def test_cross_entropy_on_padded_rows_keeps_the_row_stride():
+    from vilbert import ops as O
+    rows, n = 37, 1002
+    buf = torch.full((rows, 1004), float("nan"))
+    buf[:, :n] = _rand(rows, n, seed=5)
+    logits = buf.cuda()[:, :n]
+    labels = torch.randint(0, n, (rows,), generator=torch.Generator().manual_seed(1))
+    labels[::5] = -1
+    loss, lse, count = O.xent_fwd(logits, labels.cuda(), -1)
+    ref = torch.nn.functional.cross_entropy(buf[:, :n].double(), labels, ignore_index=-1)
+    _close(loss, ref, 1e-5, 1e-5)
+    d = O.xent_bwd(torch.ones(1).cuda(), logits, labels.cuda(), -1, lse, count)
+    assert d.stride() == (1004, 1)
+    l64 = buf[:, :n].double().requires_grad_(True)
+    torch.nn.functional.cross_entropy(l64, labels, ignore_index=-1).backward()
+    _close(d, l64.grad, 1e-5, 1e-6)
+
+
 def test_linear_is_transpose_detecting(ops):
     # asymmetric A = I-like check: y = x @ w.T with x = one-hot rows picks rows of w.T
     K, N = 64, 160

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmP p) {
 
 unsigned long long* g_dbg = nullptr;   // lab only: where block 128 of the next v2 launches stores its cycle span
 
-// GEMM arithmetic mode: 0 = exact fp32 MFMA, 3 = bf16x6, 2 = bf16x3 (number of bf16 operand planes).
+// GEMM arithmetic mode: 0 = exact fp32 MFMA, 3 = bf16x6, 2 = bf16x3, 1 = plain bf16 (number of bf16 operand planes).
 int g_gemm_mode = -1;
 
 int gemm_mode() {
@@ -261,6 +261,7 @@ int gemm_mode() {
         g_gemm_mode = 0;
         if (e != nullptr && !strcmp(e, "bf16x6")) g_gemm_mode = 3;
         if (e != nullptr && !strcmp(e, "bf16x3")) g_gemm_mode = 2;
+        if (e != nullptr && !strcmp(e, "bf16")) g_gemm_mode = 1;
     }
     return g_gemm_mode;
 }
@@ -329,7 +330,7 @@ bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
     const int forced_tm1 = code >= 100 ? code / 100 : code / 10, forced_tm2 = code >= 100 ? (code / 10) % 10 : code / 10;
     const int forced_tn = code % 10;
     if (!enabled || !vec || p.K % V2_BK != 0 || p.N % 4 != 0) return false;
-    if (!A_KC && p.M % 4 != 0) return false;
+    if (!A_KC && p.M % 4 != 0 && p.lda < (p.M + 3) / 4 * 4) return false;
     if (!B_KC && p.bseg % V2_BK != 0) return false;   // a K tile must not straddle two stacked weight segments
     for (int s = 0; s < VB_MAX_SEGMENTS; ++s)
         if (!aligned_ld(p.C[s], p.ldc) || !aligned_ld(p.bias[s], 4)) return false;
@@ -392,7 +393,7 @@ bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
 
 // splits: 1 = no split-K; < 0 = split-K launch (wgrad), choose the count; legacy_splits = count for the round-1 kernel
 template <bool A_KC, bool B_KC>
-int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits = 1) {
+int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits = 1, int vec_v2 = -1) {
     static const int flags = [] { const char* e = getenv("VB_GEMM_FLAGS"); return e ? atoi(e) : 0; }();
     p.flags = flags;
     // VB_GEMM_MODE: "f32" (default) = exact fp32 MFMA; "bf16x6" / "bf16x3" = fp32 emulated on the bf16
@@ -400,7 +401,9 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     const int planes = gemm_mode();
     V2Plan pl;
     p.dbg = g_dbg;
-    if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec, splits, pl)) {
+    // vec_v2: 16-byte loads legal for the second-generation kernel (it tolerates a row-contiguous A whose row count is
+    // not a multiple of 4 when the leading dimension leaves room for the last float4); default = same as `vec`
+    if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec_v2 < 0 ? vec : vec_v2 != 0, splits, pl)) {
         p.tiles_n = pl.tiles_n;
         p.ktiles_per_split = pl.kt_per_split;
         p.n_big = pl.big_rows * pl.tiles_n;
@@ -438,7 +441,8 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     if (planes != 0) {
         // operands split into bf16 planes on their way into LDS (gemm_planes.hip)
         if (int e = planes == 3 ? launch_gemm_planes3(st, p, vec, splits, A_KC, B_KC)
-                                : launch_gemm_planes2(st, p, vec, splits, A_KC, B_KC))
+                    : planes == 2 ? launch_gemm_planes2(st, p, vec, splits, A_KC, B_KC)
+                                  : launch_gemm_planes1(st, p, vec, splits, A_KC, B_KC))
             return e;
     } else {
         if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, block, GEMM_LDS_BYTES, st, p);
@@ -468,7 +472,7 @@ extern "C" int vb_set_gemm_tile(int code) {
 
 extern "C" int vb_set_gemm_mode(int planes) {
     const int prev = gemm_mode();
-    if (planes == 0 || planes == 2 || planes == 3) g_gemm_mode = planes;
+    if (planes >= 0 && planes <= 3) g_gemm_mode = planes;
     return prev;
 }
 
@@ -545,6 +549,20 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
             p.epi = (p.R == nullptr && !p.accumulate) ? EPI_MUL : EPI_GENERIC;
         }
         p.ktiles_per_split = (p.K + BK - 1) / BK;
+        // A contraction length that is not a multiple of 16 (the MLM decoder: 30522 out-features) would send the whole
+        // GEMM to the round-1 kernel with scalar loads: run the aligned bulk on the second-generation kernel and
+        // add the <= 15 leftover k with a second, tiny launch.
+        const int k_main = p.K / V2_BK * V2_BK;
+        if (fused && a->nseg == 1 && k_main >= 256 && k_main != p.K && p.R == nullptr && p.mul == nullptr &&
+            a->K % 4 == 0 && a->ldy % 4 == 0 && a->ldw % 4 == 0 && vb_aligned16(p.A) && vb_aligned16(p.B[0])) {
+            GemmP m = p, t = p;
+            m.K = k_main; m.bseg = k_main; m.ktiles_per_split = k_main / BK;
+            if (int e = launch_gemm<true, false>(st, m, true, 1)) return e;
+            t.K = p.K - k_main; t.bseg = t.K; t.A = p.A + k_main; t.B[0] = p.B[0] + (long)k_main * p.ldb;
+            t.accumulate = 1; t.epi = EPI_ACCUM; t.ktiles_per_split = 1;
+            if (int e = launch_gemm<true, false>(st, t, false, 1)) return e;
+            continue;
+        }
         if (int e = launch_gemm<true, false>(st, p, vec, 1)) return e;
     }
     return 0;
@@ -610,7 +628,21 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
         const bool vec = (a->seg_n % 4 == 0) && (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) &&
                          vb_aligned16(p.A) && vb_aligned16(a->X);
         p.epi = EPI_ATOMIC;
-        if (int e = launch_gemm<false, false>(st, p, vec, -1, splits)) return e;
+        // second-generation kernel: 16-byte loads along the out-feature dimension are legal when the row stride of dY
+        // leaves room for the last float4 (a [rows, 30522] gradient stored with leading dimension 30524)
+        const bool vec2 = (a->K % 4 == 0) && (a->ldy % 4 == 0) && (a->ldx % 4 == 0) && vb_aligned16(p.A) && vb_aligned16(a->X) &&
+                          (a->seg_n % 4 == 0 || (segs == 1 && a->ldy >= (a->seg_n + 3) / 4 * 4));
+        const int k_main = p.K / V2_BK * V2_BK;
+        if (vec2 && k_main >= 256 && k_main != p.K) {
+            // contraction (row count) not a multiple of 16: aligned bulk + a tiny launch for the <= 15 leftover rows
+            GemmP m = p, t = p;
+            m.K = k_main; m.bseg = k_main;
+            if (int e = launch_gemm<false, false>(st, m, vec, -1, splits, 1)) return e;
+            t.K = p.K - k_main; t.bseg = t.K; t.A = p.A + (long)k_main * p.lda; t.B[0] = p.B[0] + (long)k_main * p.ldb;
+            if (int e = launch_gemm<false, false>(st, t, false, -1, 1, 0)) return e;
+            continue;
+        }
+        if (int e = launch_gemm<false, false>(st, p, vec, -1, splits, vec2 ? 1 : 0)) return e;
     }
     return 0;
 }

@@ -210,5 +210,6 @@ int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, 
 // bf16-planes kernels (gemm_planes.hip, one object per plane count): launch for operand layouts (a_kc, b_kc)
 int launch_gemm_planes3(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);
 int launch_gemm_planes2(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);
+int launch_gemm_planes1(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);
 
 }  // namespace vbgemm

@@ -4,7 +4,7 @@
 #include "gemm_core.h"
 
 #ifndef VB_NPL
-#error "compile with -DVB_NPL=3 (bf16x6) or -DVB_NPL=2 (bf16x3)"
+#error "compile with -DVB_NPL=3 (bf16x6), -DVB_NPL=2 (bf16x3) or -DVB_NPL=1 (plain bf16 operands)"
 #endif
 
 namespace {
@@ -224,7 +224,7 @@ __device__ __forceinline__ void gemm_tile_planes(const GemmP& p, char* __restric
             for (int e = 0; e < 8; ++e) csum += reg[e >> 2][e & 3];
     };
 
-    constexpr int NPROD = NPL == 3 ? 6 : 3;
+    constexpr int NPROD = NPL == 3 ? 6 : (NPL == 2 ? 3 : 1);   // NPL 1: operands rounded to bf16, one product
     constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0};
     constexpr int PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
 
@@ -257,7 +257,7 @@ __device__ __forceinline__ void gemm_tile_planes(const GemmP& p, char* __restric
         // accumulators): NPL 3: a2b0 a0b2 a1b1 a1b0 a0b1 a0b0;  NPL 2: a1b0 a0b1 a0b0
 #pragma unroll
         for (int pr = 0; pr < NPROD; ++pr) {
-            const int pa = NPL == 3 ? PA3[pr] : PA2[pr % 3], pb = NPL == 3 ? PB3[pr] : PB2[pr % 3];
+            const int pa = NPL == 3 ? PA3[pr] : (NPL == 2 ? PA2[pr % 3] : 0), pb = NPL == 3 ? PB3[pr] : (NPL == 2 ? PB2[pr % 3] : 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

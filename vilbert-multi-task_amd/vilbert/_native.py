@@ -177,11 +177,11 @@ def set_gemm_tile(code):
     return lib().vb_set_gemm_tile(int(code))
 
 
-GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2}
+GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
 
 
 def set_gemm_mode(mode):
-    """Select the GEMM arithmetic ("f32" exact-fp32 MFMA | "bf16x6" | "bf16x3"); returns the previous name."""
+    """Select the GEMM arithmetic ("f32" exact-fp32 MFMA | "bf16x6" | "bf16x3" | "bf16"); returns the previous name."""
     prev = lib().vb_set_gemm_mode(GEMM_MODES[mode])
     return {v: k for k, v in GEMM_MODES.items()}[prev]
 

@@ -70,10 +70,12 @@ class LinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, residual, act, nseg, drop_p, *wb):
+        pad_cols = nseg < 0          # (flag folded into the sign of nseg: the output keeps a 16-byte row stride)
+        nseg = abs(nseg)
         weights, biases = list(wb[:nseg]), list(wb[nseg:])
         seed = next_seed() if drop_p > 0.0 else 0
         y, pre = ops.linear_fwd(x, weights, biases, act, residual, want_preact=act is not None, drop_p=drop_p,
-                                seed=seed)
+                                seed=seed, pad_cols=pad_cols)
         ctx.save_for_backward(x, pre, *weights, *[b for b in biases if b is not None])
         ctx.act, ctx.nseg = act, nseg
         ctx.drop = (drop_p, seed)
@@ -88,7 +90,8 @@ class LinearFn(Function):
         rest = list(ctx.saved_tensors[2 + nseg:])
         biases = [rest.pop(0) if h else None for h in ctx.has_bias]
         seg_n, K = weights[0].shape[0], weights[0].shape[1]
-        dy = dy.contiguous()
+        if not (ops._row_strided(dy) and ctx.drop[0] == 0.0 and ctx.act is None and not ctx.needs_input_grad[1]):
+            dy = dy.contiguous()     # (a row-strided gradient of padded logits feeds the GEMMs in place)
         dres = dy if ctx.needs_input_grad[1] else None
         if ctx.drop[0] > 0.0:
             dy = ops.dropout(dy, ctx.drop[0], ctx.drop[1])

@@ -14,17 +14,17 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def linear(x, weights, biases=None, act=None, residual=None, drop_p=0.0):
+def linear(x, weights, biases=None, act=None, residual=None, drop_p=0.0, pad_cols=False):
     """dropout(act(x @ cat(weights).T + cat(biases)), drop_p) (+ residual); weights / biases may be single
-    tensors; drop_p is the EFFECTIVE probability (0 in eval mode)."""
+    tensors; drop_p is the EFFECTIVE probability (0 in eval mode). pad_cols: see ops.linear_fwd."""
     if not isinstance(weights, (list, tuple)):
         weights, biases = [weights], [biases]
     if biases is None:
         biases = [None] * len(weights)
     if _needs_grad(x, residual, *weights, *biases):
-        return A.LinearFn.apply(x, residual, act, len(weights), drop_p, *weights, *biases)
+        return A.LinearFn.apply(x, residual, act, -len(weights) if pad_cols else len(weights), drop_p, *weights, *biases)
     seed = A.next_seed() if drop_p > 0.0 else 0
-    return ops.linear_fwd(x, weights, biases, act, residual, drop_p=drop_p, seed=seed)[0]
+    return ops.linear_fwd(x, weights, biases, act, residual, drop_p=drop_p, seed=seed, pad_cols=pad_cols)[0]
 
 
 def ffn(x, w1, b1, act, w2, b2, drop_p=0.0):

@@ -74,11 +74,19 @@ def _row_view(x, K):
     return x.view(-1, K), K, tuple(x.shape[:-1])
 
 
+def _row_strided(t):
+    """2-D tensor whose rows are contiguous and uniformly strided (e.g. [rows, 30522] inside a [rows, 30524] buffer)."""
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]
+
+
 def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0,
-               want_act_grad=False):
+               want_act_grad=False, pad_cols=False):
     """act(x @ cat(weights).T + cat(biases)) (+ residual).
     want_act_grad: the second return value is act'(pre-activation) instead of the pre-activation (the backward
     of the activation then is one multiply in the epilogue of linear_bwd_input(mul=...)).
+    pad_cols: a 2-D result whose width is not a multiple of 4 (the 30522-wide MLM logits) is returned as a view of a
+    buffer with the row stride rounded up to 4 floats, so that its rows (and its gradient's) stay 16-byte aligned
+    for the backward GEMMs.
 
     x: [..., K] (the last dim must be contiguous; a uniform row stride is allowed, e.g. the first-token
     view ``h[:, 0]`` of the poolers). weights: list of [n, K] with equal n; biases: list of [n] or None.
@@ -94,7 +102,13 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     x2, lda, lead = _row_view(x, K)
     M = x2.shape[0]
     n_out = nseg * seg_n
-    y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
+    ldc = n_out
+    if pad_cols and n_out % 4 != 0 and len(lead) == 1 and residual is None and not (want_preact or want_act_grad) \
+            and drop_p == 0.0:
+        ldc = (n_out + 3) // 4 * 4
+        y = torch.empty(lead + (ldc,), dtype=torch.float32, device=x.device)[:, :n_out]
+    else:
+        y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if (want_preact or want_act_grad) else None
     a = N.LinearArgs()
     a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
@@ -107,7 +121,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
         b = biases[s] if biases is not None else None
         a.bias[s] = N.dev_f32(b, "linear bias") if b is not None else None
     a.ldw = K
-    a.C, a.ldc = y.data_ptr(), n_out
+    a.C, a.ldc = y.data_ptr(), ldc
     if residual is not None:
         residual = _contig(residual)
         if residual.numel() != M * n_out:
@@ -129,12 +143,16 @@ def linear_bwd_input(dy, weights, in_features, residual=None, mul=None):
     residual: a gradient of the same shape arriving over a skip connection (added in the GEMM epilogue);
     mul: elementwise multiplier of the same shape (the saved activation derivative of the producing layer)."""
     nseg, seg_n = len(weights), weights[0].shape[0]
-    dy = _contig(dy)
+    ldy = nseg * seg_n
+    if _row_strided(dy) and dy.shape[1] == ldy:
+        ldy = dy.stride(0)            # rows of a padded buffer (pad_cols): used in place
+    else:
+        dy = _contig(dy)
     M = dy.numel() // (nseg * seg_n)
     dx = torch.empty(tuple(dy.shape[:-1]) + (in_features,), dtype=torch.float32, device=dy.device)
     a = N.LinearBwdInputArgs()
     a.M, a.K, a.nseg, a.seg_n = M, in_features, nseg, seg_n
-    a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), nseg * seg_n
+    a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), ldy
     for s in range(nseg):
         a.W[s] = N.dev_f32(weights[s], "linear weight")
     a.ldw = in_features
@@ -161,13 +179,17 @@ def linear_bwd_weight(dy, x, nseg, seg_n, want_bias, dw_out=None, db_out=None):
     per-segment target tensors (gradient-arena slices: zero-filled once per backward pass, or holding an earlier
     contribution) or None; the targets not given are slices of ONE zero-filled buffer allocated here (one fill
     launch instead of two per segment)."""
-    dy = _contig(dy)
+    ldy = nseg * seg_n
+    if _row_strided(dy) and dy.shape[1] == ldy:
+        ldy = dy.stride(0)
+    else:
+        dy = _contig(dy)
     K = x.shape[-1]
     x2, ldx, _ = _row_view(x, K)
     M = x2.shape[0]
     a = N.LinearBwdWeightArgs()
     a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
-    a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), nseg * seg_n
+    a.dY, a.ldy = N.dev_f32(dy, "linear grad_output"), ldy
     a.X, a.ldx = N.dev_f32(x2, "linear input"), ldx
     a.ldw, a.accumulate = K, 1
     wsz, bsz = (seg_n * K + 3) // 4 * 4, (seg_n + 3) // 4 * 4          # every slice stays 16-byte aligned
@@ -408,27 +430,34 @@ def xent_fwd(logits, labels, ignore_index):
     int64. Returns (loss [1]-element 0-dim view, lse [rows], count [1])."""
     if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
         raise RuntimeError("cross_entropy: expected logits [rows, n] and labels [rows]")
-    logits, labels = _contig(logits), _contig(labels)
+    if not _row_strided(logits):
+        logits = _contig(logits)
+    labels = _contig(labels)
     rows, n = logits.shape
+    ld = logits.stride(0) if rows > 1 else n
     dev = logits.device
     row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
     lse = torch.empty(rows, dtype=torch.float32, device=dev)
     out = torch.empty(2, dtype=torch.float32, device=dev)    # {loss, count}
-    N.check(N.lib().vb_xent_fwd(N.stream_ptr(), rows, n, N.dev_f32(logits, "cross_entropy logits"), n,
+    N.check(N.lib().vb_xent_fwd(N.stream_ptr(), rows, n, N.dev_f32(logits, "cross_entropy logits"), ld,
                                 N.dev_i64(labels, "cross_entropy labels"), ignore_index, row_loss.data_ptr(),
                                 lse.data_ptr(), out.data_ptr(), out.data_ptr() + 4), "vb_xent_fwd")
     return out[0], lse, out[1:]
 
 
 def xent_bwd(grad_loss, logits, labels, ignore_index, lse, count):
-    logits, labels = _contig(logits), _contig(labels)
+    if not _row_strided(logits):
+        logits = _contig(logits)
+    labels = _contig(labels)
     rows, n = logits.shape
+    ld = logits.stride(0) if rows > 1 else n
     grad_loss = _contig(grad_loss).reshape(1)
-    d = torch.empty_like(logits)
-    N.check(N.lib().vb_xent_bwd(N.stream_ptr(), rows, n, N.dev_f32(logits, "cross_entropy logits"), n,
+    # the gradient keeps the (padded) row stride of the logits
+    d = torch.empty(rows, ld, dtype=torch.float32, device=logits.device)[:, :n]
+    N.check(N.lib().vb_xent_bwd(N.stream_ptr(), rows, n, N.dev_f32(logits, "cross_entropy logits"), ld,
                                 N.dev_i64(labels, "cross_entropy labels"), ignore_index,
                                 N.dev_f32(lse, "cross_entropy lse"), N.dev_f32(grad_loss, "cross_entropy grad"),
-                                N.dev_f32(count, "cross_entropy count"), d.data_ptr(), n), "vb_xent_bwd")
+                                N.dev_f32(count, "cross_entropy count"), d.data_ptr(), ld), "vb_xent_bwd")
     return d
 
 

@@ -692,8 +692,10 @@ class BertLMPredictionHead(nn.Module):
         self.decoder.weight = bert_model_embedding_weights
         self.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
 
-    def forward(self, hidden_states):
-        return F.linear(self.transform(hidden_states), self.decoder.weight, self.bias)
+    def forward(self, hidden_states, pad_cols=False):
+        # pad_cols (internal, labelled-rows loss path): the [rows, 30522] logits live in a buffer with a 30524-float
+        # row stride, so the rows of the logits and of their gradient are 16-byte aligned for the backward GEMMs
+        return F.linear(self.transform(hidden_states), self.decoder.weight, self.bias, pad_cols=pad_cols)
 
 
 class BertOnlyMLMHead(nn.Module):
@@ -977,7 +979,7 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
                                              ignore_index=-1)
 
         rows_t = sequence_output_t.reshape(-1, sequence_output_t.size(-1)).index_select(0, idx_t)
-        masked_lm_loss = F.cross_entropy(cls.predictions(rows_t), labels_t, ignore_index=-1)
+        masked_lm_loss = F.cross_entropy(cls.predictions(rows_t, pad_cols=True), labels_t, ignore_index=-1)
 
         rows_v = sequence_output_v.reshape(-1, sequence_output_v.size(-1)).index_select(0, idx_v)
         scores_v = cls.imagePredictions(rows_v)
