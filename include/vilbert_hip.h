@@ -41,6 +41,7 @@ extern "C" {
 #define VB_ACT_NONE 0
 #define VB_ACT_GELU 1  /* x*0.5*(1+erf(x/sqrt(2))) - vilbert.py:111-117 */
 #define VB_ACT_RELU 2  /* poolers, vilbert.py:1114,1129 */
+#define VB_ACT_SWISH 3 /* x*sigmoid(x) - vilbert.py:120-121 (ACT2FN["swish"]; no shipped config uses it) */
 
 #define VB_MAX_SEGMENTS 4
 #define VB_MAX_KEYS 320     /* longest key sequence one attention launch handles */

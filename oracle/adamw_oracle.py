@@ -3,8 +3,12 @@
 The reference pins ``pytorch-transformers==1.0.0`` (/root/reference/requirements.txt:1) and calls
 ``AdamW(params, lr, betas=(0.9, 0.98))`` (train_concap.py:465-470) / ``AdamW(params, lr, correct_bias=False)``
 (train_tasks.py:426). The package is not vendored in the reference tree and not installed here, so this is a
-restatement of its published algorithm (one torch op per line of the original ``step``); PARITY UNPINNED:
-there is no golden vector from the real package to check it against.
+restatement of its published algorithm (one torch op per line of the original ``step``). The real package cannot be
+run here; the restatement is PINNED INDIRECTLY: tests/golden/adamw_trajectory.npz holds 5-step trajectories derived
+from torch.optim.AdamW through the two analytic differences of the algorithms (eps placement under bias correction,
+decay before / after the update - tests/golden/make_adamw_golden.py), for both correct_bias settings, with and
+without decay; tests/test_optim.py checks this file and, independently, the native kernel against them, and the
+warm-up schedules against the transformers package installed in the image.
 """
 import math
 

@@ -206,7 +206,8 @@ NO_DROPOUT = dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, v_h
 
 @pytest.mark.parametrize("kind", ["pretraining", "vltasks"])
 @pytest.mark.parametrize("over", [{}, {"task_specific_tokens": True}, {"dynamic_attention": True, "fusion_method": "sum"},
-                                  {"model": "roberta", "type_vocab_size": 1}])   # roberta_base_6layer_6connect.json
+                                  {"model": "roberta", "type_vocab_size": 1},    # roberta_base_6layer_6connect.json
+                                  {"hidden_act": "swish", "v_hidden_act": "swish"}])   # ACT2FN["swish"], vilbert.py:120-121
 def test_model_gradients_match_oracle_autograd(kind, over):
     if kind == "pretraining" and over.get("task_specific_tokens"):
         pytest.skip("the pre-training wrapper does not pass task ids (reference vilbert.py:1486-1495)")

@@ -158,15 +158,22 @@ def test_linear_unaligned_k_scalar_path(ops):
     _close(y, x.double() @ w.double().t() + b.double())
 
 
-@pytest.mark.parametrize("act", ["gelu", "relu"])
+@pytest.mark.parametrize("act", ["gelu", "relu", "swish"])
 def test_linear_act_residual_preact(ops, act):
     M, N, K = 200, 256, 96
     x, w, b, r = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1), _rand(N, seed=9), _rand(M, N, seed=10)
     y, pre = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()], act=act, residual=r.cuda(), want_preact=True)
     pre64 = x.double() @ w.double().t() + b.double()
-    act64 = _gelu64(pre64) if act == "gelu" else torch.relu(pre64)
+    act64 = _gelu64(pre64) if act == "gelu" else (torch.relu(pre64) if act == "relu" else pre64 * torch.sigmoid(pre64))
     _close(pre, pre64)
     _close(y, act64 + r.double())
+    # activation derivative (saved for the fused backward) and the stand-alone activation backward
+    _, d = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()], act=act, want_act_grad=True)
+    p64 = pre64.clone().requires_grad_(True)
+    (_gelu64(p64) if act == "gelu" else (torch.relu(p64) if act == "relu" else p64 * torch.sigmoid(p64))).sum().backward()
+    _close(d, p64.grad)
+    dy = _rand(M, N, seed=12)
+    _close(ops.act_bwd(dy.cuda(), pre, act), dy.double() * p64.grad)
 
 
 @pytest.mark.parametrize("H", [128, 64, 96, 20])

@@ -29,6 +29,69 @@ def test_schedules_and_import_shim():
         AdamW([w], lr=-1.0)
 
 
+def _golden_adamw():
+    import importlib.util
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_adamw_golden", os.path.join(here, "make_adamw_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with np.load(os.path.join(here, "adamw_trajectory.npz")) as z:
+        return mod, {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("correct_bias", [True, False])
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adamw_oracle_is_pinned_to_torch_adamw_trajectories(correct_bias, wd):
+    """oracle/adamw_oracle.py (restatement of the un-vendored pytorch-transformers 1.0.0 AdamW) against trajectories
+    derived from torch.optim.AdamW through the two analytic differences of the algorithms (eps placement, decay order -
+    tests/golden/make_adamw_golden.py): 5 steps, both correct_bias settings, with and without decay."""
+    mod, gold = _golden_adamw()
+    p0, gs = mod.grads()
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for t, g in enumerate(gs, 1):
+        ao.adamw_step(p, g, m, v, t, mod.LR, mod.BETAS, mod.EPS, wd, correct_bias)
+    want = gold["p_cb%d_wd%g" % (int(correct_bias), wd)]
+    assert (p - want).abs().max().item() <= 1e-12 * max(1.0, want.abs().max().item())
+    assert torch.allclose(m, gold["exp_avg"], atol=1e-15) and torch.allclose(v, gold["exp_avg_sq"], atol=1e-15)
+
+
+def test_warmup_schedules_match_the_transformers_package():
+    """WarmupLinearSchedule / WarmupConstantSchedule (pytorch-transformers 1.0.0 names) against their descendants in
+    the transformers package installed here (same lambdas under new names)."""
+    tr = pytest.importorskip("transformers.optimization")
+    lin = getattr(tr, "_get_linear_schedule_with_warmup_lr_lambda", None)
+    const = getattr(tr, "_get_constant_schedule_with_warmup_lr_lambda", None)
+    if lin is None or const is None:
+        pytest.skip("transformers version without the schedule lambdas")
+    from vilbert.optim import AdamW, WarmupConstantSchedule, WarmupLinearSchedule
+    w = torch.nn.Parameter(torch.zeros(2))
+    s_lin = WarmupLinearSchedule(AdamW([w], lr=1.0), warmup_steps=7, t_total=40)
+    s_const = WarmupConstantSchedule(AdamW([w], lr=1.0), warmup_steps=5)
+    for step in range(45):
+        assert s_lin.lr_lambda(step) == pytest.approx(lin(step, num_warmup_steps=7, num_training_steps=40))
+        assert ao.warmup_linear(step, 7, 40) == pytest.approx(lin(step, num_warmup_steps=7, num_training_steps=40))
+        assert s_const.lr_lambda(step) == pytest.approx(const(step, num_warmup_steps=5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("correct_bias", [True, False])
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_native_adamw_matches_the_torch_derived_golden_trajectories(correct_bias, wd):
+    """The native multi-tensor kernel against the SAME goldens, independently of the oracle."""
+    from vilbert.optim import AdamW
+    mod, gold = _golden_adamw()
+    p0, gs = mod.grads()
+    p = torch.nn.Parameter(p0.float().cuda())
+    opt = AdamW([p], lr=mod.LR, betas=mod.BETAS, eps=mod.EPS, weight_decay=wd, correct_bias=correct_bias)
+    for g in gs:
+        p.grad = g.float().cuda()
+        opt.step()
+    want = gold["p_cb%d_wd%g" % (int(correct_bias), wd)]
+    assert (p.detach().cpu().double() - want).abs().max().item() <= 3e-6 * max(1.0, want.abs().max().item())
+
+
 def test_adamw_has_no_cpu_fallback():
     from vilbert.optim import AdamW
     w = torch.nn.Parameter(torch.ones(8))

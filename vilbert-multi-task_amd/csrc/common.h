@@ -35,3 +35,13 @@ __device__ __forceinline__ float gelu_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }
+
+__device__ __forceinline__ float swish_act(float x) {
+    // vilbert.py:120-121  x * sigmoid(x)
+    return x / (1.0f + expf(-x));
+}
+
+__device__ __forceinline__ float swish_grad(float x) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    return s + x * s * (1.0f - s);
+}

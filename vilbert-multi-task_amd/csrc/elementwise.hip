@@ -13,7 +13,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long n4, const f32x4* __re
         const f32x4 g = dy[i], x = pre[i];
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = ACT == VB_ACT_GELU ? g[e] * gelu_grad(x[e]) : (x[e] > 0.f ? g[e] : 0.f);
+        for (int e = 0; e < 4; ++e)
+            o[e] = ACT == VB_ACT_GELU ? g[e] * gelu_grad(x[e])
+                   : (ACT == VB_ACT_SWISH ? g[e] * swish_grad(x[e]) : (x[e] > 0.f ? g[e] : 0.f));
         dx[i] = o;
     }
 }
@@ -60,6 +62,10 @@ extern "C" int vb_act_bwd(void* stream, int64_t n, int32_t act, const float* dy,
         hipLaunchKernelGGL(act_bwd_kernel<VB_ACT_RELU>, dim3(grid_for(n4)), dim3(256), 0, st, n4,
                            reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(preact),
                            reinterpret_cast<f32x4*>(dx));
+    else if (act == VB_ACT_SWISH)
+        hipLaunchKernelGGL(act_bwd_kernel<VB_ACT_SWISH>, dim3(grid_for(n4)), dim3(256), 0, st, n4,
+                           reinterpret_cast<const f32x4*>(dy), reinterpret_cast<const f32x4*>(preact),
+                           reinterpret_cast<f32x4*>(dx));
     else
         return VB_E_BADARG;
     VB_LAUNCH_CHECK();
@@ -98,7 +104,8 @@ __global__ __launch_bounds__(256) void act_grad_inplace_kernel(long rows, int co
     if (i >= rows * cols) return;
     float* q = d + (i / cols) * ld + (i % cols);
     const float v = *q;
-    *q = act == VB_ACT_GELU ? gelu_grad(v) : (act == VB_ACT_RELU ? (v > 0.f ? 1.f : 0.f) : 1.f);
+    *q = act == VB_ACT_GELU ? gelu_grad(v)
+         : (act == VB_ACT_RELU ? (v > 0.f ? 1.f : 0.f) : (act == VB_ACT_SWISH ? swish_grad(v) : 1.f));
 }
 
 __global__ __launch_bounds__(256) void mul_inplace_kernel(long rows, int cols, float* __restrict__ c, long ldc,

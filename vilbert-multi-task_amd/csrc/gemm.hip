@@ -480,7 +480,7 @@ extern "C" int vb_linear_fwd(void* stream, const vb_linear_args* a) {
     if (a == nullptr || a->A == nullptr || a->C == nullptr) return VB_E_BADARG;
     if (a->M <= 0 || a->K <= 0 || a->seg_n <= 0) return VB_E_BADARG;
     if (a->nseg < 1 || a->nseg > VB_MAX_SEGMENTS) return VB_E_SEGMENT;
-    if (a->act < VB_ACT_NONE || a->act > VB_ACT_RELU) return VB_E_BADARG;
+    if (a->act < VB_ACT_NONE || a->act > VB_ACT_SWISH) return VB_E_BADARG;
     GemmP p{};
     p.M = a->M; p.K = a->K; p.N = a->nseg * a->seg_n;
     p.A = a->A; p.lda = a->lda;

@@ -145,6 +145,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
                 if (p.P != nullptr) p.P[(long)row * p.ldp + col] = v;
                 if (p.act == VB_ACT_GELU) v = gelu_erf(v);
                 else if (p.act == VB_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == VB_ACT_SWISH) v = swish_act(v);
                 if (p.drop_p > 0.f) v = vb_keep(seed, (uint64_t)((long)row * p.N + col), p.drop_p) ? v * p.drop_scale : 0.f;
                 if (p.R != nullptr && lead) v += p.R[(long)row * p.ldr + col];
                 float* c = cptr + (long)dr * p.ldc + j * 32;

@@ -40,18 +40,21 @@ template <int TM1, int TM2, int TN>
 int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
     using Cfg = V2Cfg<TM1, TN, A_KC, B_KC>;   // TM1 >= TM2: the taller tile sets the LDS size and the register budget
     dim3 grid(tiles, splits), block(256);
+    // lab knob: extra dynamic LDS per block = fewer co-resident blocks per CU (occupancy experiments)
+    static const int lds_pad = [] { const char* e = getenv("VB_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
+    const int lds_bytes = Cfg::LDS_BYTES + lds_pad;
 #ifdef VB_GEMM_LAB
     // ablation variants for tools/gemm_lab (make LAB=1): 1 = no staging, 2 = no barrier, 4 = no global loads,
     // 5 = loads do not advance, 6 = contiguous load pattern - they time parts of the K loop and give WRONG results
     static const int abl = [] { const char* e = getenv("VB_GEMM_ABL"); return e ? atoi(e) : 0; }();
-    if (abl == 1) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 1>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 2) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 2>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 4) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 4>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 5) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 5>), grid, block, Cfg::LDS_BYTES, st, p);
-    else if (abl == 6) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 6>), grid, block, Cfg::LDS_BYTES, st, p);
+    if (abl == 1) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 1>), grid, block, lds_bytes, st, p);
+    else if (abl == 2) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 2>), grid, block, lds_bytes, st, p);
+    else if (abl == 4) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 4>), grid, block, lds_bytes, st, p);
+    else if (abl == 5) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 5>), grid, block, lds_bytes, st, p);
+    else if (abl == 6) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 6>), grid, block, lds_bytes, st, p);
     else
 #endif
-        hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 0>), grid, block, Cfg::LDS_BYTES, st, p);
+        hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 0>), grid, block, lds_bytes, st, p);
     VB_LAUNCH_CHECK();
     return 0;
 }

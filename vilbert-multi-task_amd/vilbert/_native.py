@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libvilbert_hip.so")
 
 VB_MAX_SEGMENTS = 4
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU}
+ACT_SWISH = 3
+ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU, "relu": ACT_RELU, "swish": ACT_SWISH}
 
 _c_f32p = ctypes.c_void_p  # device pointers are passed as plain addresses
 

@@ -29,7 +29,7 @@ from .utils import PreTrainedModel
 
 logger = logging.getLogger(__name__)
 
-_SUPPORTED_ACTS = ("gelu", "relu")
+_SUPPORTED_ACTS = ("gelu", "relu", "swish")
 
 
 class BertConfig(object):
