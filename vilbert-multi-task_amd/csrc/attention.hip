@@ -625,6 +625,215 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
     }
 }
 
+// Backward in ONE launch, short sequences (round 2): K, V, Q and dO of the (sample, head) are staged once - exactly
+// n rows each, unpadded, [n][D + 4] - so the block moves 4 reads + 3 writes of H floats per token row instead of the 8
+// + 3 of the two-pass version. Phase 1 (one wave per 16 queries): dP, D = rowsum(P dP) (kept in LDS), dS, dQ = dS K.
+// Phase 2 (one wave per 16 keys): dV = P^T dO, dK = dS^T Q. Rows past the end of a tile are read CLAMPED to the last
+// real row (no zero padding, which would cost a third block of LDS at head_dim 128): every such value only ever
+// meets a factor that is exactly 0 (masked score / probability), and the clamped data is finite model data.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_in) {
+    AttnP p = p_in;
+    p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
+    extern __shared__ __attribute__((aligned(16))) float smem_att[];
+    constexpr int LD = D + 4, DS = D / 16, NT = LDS_MAX_ROWS / 16, V4 = D / 4;
+    float* sK = smem_att;
+    float* sV = sK + p.n_k * LD;
+    float* sQ = sV + p.n_k * LD;
+    float* sO = sQ + p.n_q * LD;
+    float* sD = sO + p.n_q * LD;          // [n_q] D vector
+    const long bh = blockIdx.x;
+    const int h = (int)(bh % p.heads), b = (int)(bh / p.heads);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int nkt = p.n_kt;
+    const bool drop = p.drop_p > 0.f;
+
+    {   // stage the four operand blocks (coalesced 16-byte loads, rows of D floats)
+        const float* gk = p.K + (long)b * p.n_k * p.ldk + h * D;
+        const float* gv = p.V + (long)b * p.n_k * p.ldv + h * D;
+        const float* gq = p.Q + (long)b * p.n_q * p.ldq + h * D;
+        const float* go = p.dO + (long)b * p.n_q * p.lddo + h * D;
+        for (int f = threadIdx.x; f < p.n_k * V4; f += 256) {
+            const int r = f / V4, c4 = (f % V4) * 4;
+            *reinterpret_cast<f32x4*>(sK + r * LD + c4) = *reinterpret_cast<const f32x4*>(gk + (long)r * p.ldk + c4);
+            *reinterpret_cast<f32x4*>(sV + r * LD + c4) = *reinterpret_cast<const f32x4*>(gv + (long)r * p.ldv + c4);
+        }
+        for (int f = threadIdx.x; f < p.n_q * V4; f += 256) {
+            const int r = f / V4, c4 = (f % V4) * 4;
+            *reinterpret_cast<f32x4*>(sQ + r * LD + c4) = *reinterpret_cast<const f32x4*>(gq + (long)r * p.ldq + c4);
+            *reinterpret_cast<f32x4*>(sO + r * LD + c4) = *reinterpret_cast<const f32x4*>(go + (long)r * p.lddo + c4);
+        }
+    }
+    __syncthreads();
+    const float* mrow = p.mask != nullptr ? p.mask + (long)b * p.n_k : nullptr;
+    const float* lse_g = p.lse + bh * p.n_q;
+
+    // ---- phase 1: dQ and D, one wave per 16 queries ----------------------------------------------------------------
+    for (int qt = wave; qt < p.n_qt; qt += 4) {
+        const int q_row = min(qt * 16 + c, p.n_q - 1);
+        f32x4 qf[DS], dof[DS];
+        load_frag_lds<DS>(qf, sQ + q_row * LD + 4 * g);
+        load_frag_lds<DS>(dof, sO + q_row * LD + 4 * g);
+        const long prow = (bh * p.n_q + q_row) * p.n_k;
+        const float lse = lse_g[q_row];
+        f32x4 st[NT], dp[NT];
+        float dsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt) {
+                const int krow = min(kt * 16 + c, p.n_k - 1);
+                f32x4 kf[DS], vf[DS];
+                load_frag_lds<DS>(kf, sK + krow * LD + 4 * g);
+                load_frag_lds<DS>(vf, sV + krow * LD + 4 * g);
+                const f32x4 sacc = dot_tile<DS>(kf, qf);
+                f32x4 dacc = dot_tile<DS>(vf, dof);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * g + r;
+                    float pv = 0.f, d = 0.f;
+                    if (key < p.n_k) {
+                        float sv = __fmul_rn(sacc[r], p.scale);
+                        if (mrow != nullptr) sv = __fadd_rn(sv, mrow[key]);
+                        pv = expf(sv - lse);
+                        d = dacc[r];
+                        if (drop) d = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p) ? d * p.drop_scale : 0.f;
+                    }
+                    st[kt][r] = pv;
+                    dacc[r] = d;
+                    dsum += pv * d;
+                }
+                dp[kt] = dacc;
+            }
+        }
+        dsum = group_sum(dsum);
+        if (g == 0 && qt * 16 + c < p.n_q) sD[qt * 16 + c] = dsum;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * (dp[kt][r] - dsum) * p.scale;
+        // dQ = dS K  (B operand rows from LDS, clamped past n_k where dS is exactly 0)
+        f32x4 oacc[DS];
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt < nkt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* rp = sK + min(kt * 16 + 4 * g + r, p.n_k - 1) * LD + c;
+                    float vv[DS];
+#pragma unroll
+                    for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
+#pragma unroll
+                    for (int dt = 0; dt < DS; ++dt)
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * g + r;
+            if (q < p.n_q) {
+                float* op = p.dQ + ((long)b * p.n_q + q) * p.lddq + h * D + c;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) op[16 * dt] = oacc[dt][r];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: dK and dV, one wave per 16 keys -------------------------------------------------------------------
+    for (int kt = wave; kt < p.n_kt; kt += 4) {
+        const int key = kt * 16 + c;
+        const int k_row = min(key, p.n_k - 1);
+        const bool key_ok = key < p.n_k;
+        f32x4 kf[DS], vf[DS];
+        load_frag_lds<DS>(kf, sK + k_row * LD + 4 * g);
+        load_frag_lds<DS>(vf, sV + k_row * LD + 4 * g);
+        const float madd = mrow != nullptr ? mrow[k_row] : 0.f;
+        f32x4 dk[DS], dv[DS];
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt) {
+            dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int qt = 0; qt < p.n_qt; ++qt) {
+            const int qrow_c = min(qt * 16 + c, p.n_q - 1);
+            f32x4 qf[DS], dof[DS];
+            load_frag_lds<DS>(qf, sQ + qrow_c * LD + 4 * g);
+            load_frag_lds<DS>(dof, sO + qrow_c * LD + 4 * g);
+            const f32x4 s = dot_tile<DS>(qf, kf);
+            const f32x4 dpr = dot_tile<DS>(dof, vf);
+            float pd[4], dsv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + 4 * g + r;
+                float dsr = 0.f, pdr = 0.f;
+                if (q < p.n_q && key_ok) {
+                    const float sv = __fadd_rn(__fmul_rn(s[r], p.scale), madd);
+                    const float pv = expf(sv - lse_g[q]);
+                    float d = dpr[r];
+                    pdr = pv;
+                    if (drop) {
+                        const bool keep = vb_keep(p.seed, (uint64_t)((bh * p.n_q + q) * p.n_k + key), p.drop_p);
+                        d = keep ? d * p.drop_scale : 0.f;
+                        pdr = keep ? pv * p.drop_scale : 0.f;
+                    }
+                    dsr = pv * (d - sD[q]) * p.scale;
+                }
+                pd[r] = pdr;
+                dsv[r] = dsr;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qr = min(qt * 16 + 4 * g + r, p.n_q - 1);
+                const float* dop = sO + qr * LD + c;
+                const float* qp = sQ + qr * LD + c;
+                float dov[DS], qv[DS];
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    dov[dt] = dop[16 * dt];
+                    qv[dt] = qp[16 * dt];
+                }
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[r], dov[dt], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[r], qv[dt], dk[dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = kt * 16 + 4 * g + r;
+            if (kk < p.n_k) {
+                float* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
+                float* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
+#pragma unroll
+                for (int dt = 0; dt < DS; ++dt) {
+                    kp[16 * dt] = dk[dt][r];
+                    vp[16 * dt] = dv[dt][r];
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_bwd_fused_lds(hipStream_t st, const AttnP& p) {
+    const int bytes = ((2 * p.n_k + 2 * p.n_q) * (D + 4) + LDS_MAX_ROWS) * 4;
+    // up to 4 x 48 x 132 floats = 101 KiB at head_dim 128: above the 64 KiB a kernel gets by default
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_lds_kernel<D>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL((attn_bwd_fused_lds_kernel<D>), dim3((unsigned)(p.batch * p.heads)), dim3(256), bytes, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
 inline bool use_lds_path(const AttnP& p) {
     static const int on = [] { const char* e = getenv("VB_ATTN_LDS"); return e ? atoi(e) : 1; }();
     return on && p.n_q <= LDS_MAX_ROWS && p.n_k <= LDS_MAX_ROWS && p.q_bstride == p.n_q && p.kv_bstride == p.n_k;
@@ -719,6 +928,16 @@ extern "C" int vb_attention_bwd(void* stream, const vb_attention_args* a, const 
     p.dvec = gr->dvec;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int e = 0;
+    static const int fused = [] { const char* ev = getenv("VB_ATTN_FUSED_BWD"); return ev ? atoi(ev) : 1; }();
+    if (fused && use_lds_path(p) && (gr->lddq | gr->lddk | gr->lddv) % 4 == 0) {
+        // short sequences: the whole backward in one launch (K, V, Q, dO staged once)
+        switch (a->head_dim) {
+            case 32: return launch_bwd_fused_lds<32>(st, p);
+            case 64: return launch_bwd_fused_lds<64>(st, p);
+            case 128: return launch_bwd_fused_lds<128>(st, p);
+            default: return VB_E_RANGE;
+        }
+    }
     p.total = (long)a->batch * a->heads * p.n_qt;
     switch (a->head_dim) {
         case 32: e = launch_q<32, true>(st, p); break;
