@@ -354,19 +354,25 @@ def main():
     # products per fp32 product; passes the same parity tests) - reported beside the primary number.
     alt = None
     if args.gemm_mode == "f32" and world == 1 and not args.no_alt_mode and not args.graph:
-        _native.set_gemm_mode("bf16x6")
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        alt_steps = max(3, args.steps // 2)
-        for _ in range(alt_steps):
-            step()
-        torch.cuda.synchronize()
-        alt_ms = 1e3 * (time.perf_counter() - ta) / alt_steps
-        alt = {"mode": "bf16x6", "value": round(B / (alt_ms * 1e-3), 2), "unit": "samples/s",
-               "ms_per_step": round(alt_ms, 3), "steps": alt_steps,
-               "note": "opt-in (--gemm-mode bf16x6 / VB_GEMM_MODE): same parity tests pass; GEMM ceiling 2500/6 = 417 TF"}
+        alt = {}
+        notes = {"bf16x6": "opt-in (--gemm-mode bf16x6 / VB_GEMM_MODE): fp32 operands split into 3 bf16 planes, 6 MFMA "
+                           "products, fp32-class result - the same parity tests pass; GEMM ceiling 2500/6 = 417 TF",
+                 "bf16": "opt-in reduced-precision mode (BASELINE configs[4] direction): operands rounded to bf16, one "
+                         "MFMA product, fp32 accumulate, fp32 tensors in HBM; NOT inside the 1e-4 parity bar (measured "
+                         "error ~1e-2 of the output range, tests/test_gemm_modes_gpu.py); bf16 MFMA peak 2500 TF"}
+        for mode in ("bf16x6", "bf16"):
+            _native.set_gemm_mode(mode)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            alt_steps = max(3, args.steps // 2)
+            for _ in range(alt_steps):
+                step()
+            torch.cuda.synchronize()
+            alt_ms = 1e3 * (time.perf_counter() - ta) / alt_steps
+            alt[mode] = {"value": round(B / (alt_ms * 1e-3), 2), "unit": "samples/s", "ms_per_step": round(alt_ms, 3),
+                         "steps": alt_steps, "note": notes[mode]}
         _native.set_gemm_mode("f32")
 
     # PCIe-inclusive leg (opt-in): raw worker-shaped numpy batches on the host -> pinned staging -> async H2D on
@@ -494,8 +500,8 @@ def main():
         }
         line["config"]["gemm_mode"] = args.gemm_mode
         line.update(extra)
-        if alt is not None:
-            line["alt_gemm_mode"] = alt
+        if alt:
+            line["alt_gemm_modes"] = alt
         if host_leg is not None:
             line["host_inputs"] = host_leg
         if args.gemm_mode != "f32":

@@ -193,6 +193,15 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
         }
     }
     long a_stepv = a_step;
+    if (ABL == 7) {
+        // timing experiment only (wrong results): every lane of the block loads the SAME 16 bytes
+#pragma unroll
+        for (int s = 0; s < SA; ++s) ga[s] = p.A + (long)(blockIdx.x % 64) * 65536;
+#pragma unroll
+        for (int s = 0; s < SB; ++s)
+            if (B_KC) gb[s] = p.B[0] + (long)(blockIdx.x % 4) * 65536;
+        a_stepv = 0;
+    }
     if (ABL == 6) {
         // timing experiment only (wrong results): fully contiguous 4 KiB-per-slot loads instead of 64-byte row pieces
 #pragma unroll
@@ -221,7 +230,7 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
             if (ABL != 5) ga[u] += a_stepv;
         } else if (B_KC) {
             rb[set][u - SA] = *reinterpret_cast<const f32x4*>(gb[u - SA]);
-            if (ABL != 5) gb[u - SA] += ABL == 6 ? 2048 : V2_BK;
+            if (ABL != 5 && ABL != 7) gb[u - SA] += ABL == 6 ? 2048 : V2_BK;
         } else {
             // segments stacked along K (dgrad through stacked weights); bseg is a multiple of 16
             const float* __restrict__ bb = p.B[b_seg] + (long)b_krem * p.ldb;
@@ -235,6 +244,11 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
     const bool a_last_ok = (BM * 4) % 256 == 0 || tid + 256 * (SA - 1) < BM * 4;
     const bool b_last_ok = (BN * 4) % 256 == 0 || tid + 256 * (SB - 1) < BN * 4;
     auto store_slot = [&](int u, float* __restrict__ st, int set) {
+        if (ABL == 3) {   // lab: wait for the staged data where the LDS write would be, write nothing
+            if (u < SA) asm volatile("" ::"v"(ra[set][u]));
+            else asm volatile("" ::"v"(rb[set][u - SA]));
+            return;
+        }
         // slots past the end of a 96-row tile (1.5 float4 per thread) go to the dump area instead of branching
         if (u < SA) {
             float* dst = (u + 1 < SA || a_last_ok) ? st + la[u] : smem + Cfg::DUMP + tid * 4;

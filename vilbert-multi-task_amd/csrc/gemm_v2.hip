@@ -52,6 +52,8 @@ int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
     else if (abl == 4) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 4>), grid, block, lds_bytes, st, p);
     else if (abl == 5) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 5>), grid, block, lds_bytes, st, p);
     else if (abl == 6) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 6>), grid, block, lds_bytes, st, p);
+    else if (abl == 3) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 3>), grid, block, lds_bytes, st, p);
+    else if (abl == 7) hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 7>), grid, block, lds_bytes, st, p);
     else
 #endif
         hipLaunchKernelGGL((gemm_v2_kernel<TM1, TM2, TN, 0>), grid, block, lds_bytes, st, p);
