@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
 // real row (no zero padding, which would cost a third block of LDS at head_dim 128): every such value only ever
 // meets a factor that is exactly 0 (masked score / probability), and the clamped data is finite model data.
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_in) {
+__global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_in, const int ps_off) {
     AttnP p = p_in;
     p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
     extern __shared__ __attribute__((aligned(16))) float smem_att[];
@@ -641,7 +641,13 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
     float* sV = sK + p.n_k * LD;
     float* sQ = sV + p.n_k * LD;
     float* sO = sQ + p.n_q * LD;
-    float* sD = sO + p.n_q * LD;          // [n_q] D vector
+    float* sD = sO + p.n_q * LD;          // [n_q] D vector (unused since phase 2 reads dS; kept for the lse-free layout)
+    // phase-1 results handed to phase 2 through LDS: Pd[q][key] (probabilities incl. the dropout mask / scale) and
+    // dS[q][key], row stride LDP. They live at float offset ps_off: over the V block when they fit there (V is dead
+    // after phase 1 - this keeps head_dim 128 at two blocks per CU), else behind the D vector.
+    const int LDP = (p.n_k + 3) / 4 * 4 + 4;
+    float* sP = smem_att + ps_off;
+    float* sS = sP + p.n_q * LDP;
     const long bh = blockIdx.x;
     const int h = (int)(bh % p.heads), b = (int)(bh / p.heads);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -669,19 +675,23 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
     const float* mrow = p.mask != nullptr ? p.mask + (long)b * p.n_k : nullptr;
     const float* lse_g = p.lse + bh * p.n_q;
 
-    // ---- phase 1: dQ and D, one wave per 16 queries ----------------------------------------------------------------
-    for (int qt = wave; qt < p.n_qt; qt += 4) {
+    // ---- phase 1: dQ, Pd and dS; one wave per 16 queries (n_q <= 48: at most one tile per wave) --------------------
+    const int qt = wave;
+    const bool has_q = qt < p.n_qt;
+    f32x4 pdm[NT], dsm[NT];      // Pd and dS of this wave's 16 queries: lane (c = query, g) holds keys 16 kt + 4 g + r
+    if (has_q) {
         const int q_row = min(qt * 16 + c, p.n_q - 1);
         f32x4 qf[DS], dof[DS];
         load_frag_lds<DS>(qf, sQ + q_row * LD + 4 * g);
         load_frag_lds<DS>(dof, sO + q_row * LD + 4 * g);
         const long prow = (bh * p.n_q + q_row) * p.n_k;
         const float lse = lse_g[q_row];
-        f32x4 st[NT], dp[NT];
+        f32x4 dp[NT];
         float dsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pdm[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dsm[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
             dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (kt < nkt) {
                 const int krow = min(kt * 16 + c, p.n_k - 1);
@@ -693,15 +703,21 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * 16 + 4 * g + r;
-                    float pv = 0.f, d = 0.f;
+                    float pv = 0.f, d = 0.f, pd = 0.f;
                     if (key < p.n_k) {
                         float sv = __fmul_rn(sacc[r], p.scale);
                         if (mrow != nullptr) sv = __fadd_rn(sv, mrow[key]);
                         pv = expf(sv - lse);
                         d = dacc[r];
-                        if (drop) d = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p) ? d * p.drop_scale : 0.f;
+                        pd = pv;
+                        if (drop) {
+                            const bool keep = vb_keep(p.seed, (uint64_t)(prow + key), p.drop_p);
+                            d = keep ? d * p.drop_scale : 0.f;
+                            pd = keep ? pv * p.drop_scale : 0.f;
+                        }
                     }
-                    st[kt][r] = pv;
+                    dsm[kt][r] = pv;
+                    pdm[kt][r] = pd;
                     dacc[r] = d;
                     dsum += pv * d;
                 }
@@ -709,12 +725,11 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
             }
         }
         dsum = group_sum(dsum);
-        if (g == 0 && qt * 16 + c < p.n_q) sD[qt * 16 + c] = dsum;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
             if (kt < nkt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[kt][r] = st[kt][r] * (dp[kt][r] - dsum) * p.scale;
+                for (int r = 0; r < 4; ++r) dsm[kt][r] = dsm[kt][r] * (dp[kt][r] - dsum) * p.scale;
         // dQ = dS K  (B operand rows from LDS, clamped past n_k where dS is exactly 0)
         f32x4 oacc[DS];
 #pragma unroll
@@ -730,7 +745,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
                     for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
 #pragma unroll
                     for (int dt = 0; dt < DS; ++dt)
-                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsm[kt][r], vv[dt], oacc[dt], 0, 0, 0);
                 }
             }
         }
@@ -744,53 +759,36 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
             }
         }
     }
+    __syncthreads();            // every wave is done reading K and V: their LDS may be overwritten
+    if (has_q && qt * 16 + c < p.n_q) {
+        float* pr = sP + (qt * 16 + c) * LDP + 4 * g;
+        float* sr = sS + (qt * 16 + c) * LDP + 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < nkt && kt * 16 + 4 * g < LDP) {
+                *reinterpret_cast<f32x4*>(pr + kt * 16) = pdm[kt];
+                *reinterpret_cast<f32x4*>(sr + kt * 16) = dsm[kt];
+            }
+    }
     __syncthreads();
 
-    // ---- phase 2: dK and dV, one wave per 16 keys -------------------------------------------------------------------
+    // ---- phase 2: dV = Pd^T dO, dK = dS^T Q; one wave per 16 keys ---------------------------------------------------
     for (int kt = wave; kt < p.n_kt; kt += 4) {
-        const int key = kt * 16 + c;
-        const int k_row = min(key, p.n_k - 1);
-        const bool key_ok = key < p.n_k;
-        f32x4 kf[DS], vf[DS];
-        load_frag_lds<DS>(kf, sK + k_row * LD + 4 * g);
-        load_frag_lds<DS>(vf, sV + k_row * LD + 4 * g);
-        const float madd = mrow != nullptr ? mrow[k_row] : 0.f;
+        const int key = min(kt * 16 + c, p.n_k - 1);      // columns past n_k: clamped, their results are not stored
         f32x4 dk[DS], dv[DS];
 #pragma unroll
         for (int dt = 0; dt < DS; ++dt) {
             dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        for (int qt = 0; qt < p.n_qt; ++qt) {
-            const int qrow_c = min(qt * 16 + c, p.n_q - 1);
-            f32x4 qf[DS], dof[DS];
-            load_frag_lds<DS>(qf, sQ + qrow_c * LD + 4 * g);
-            load_frag_lds<DS>(dof, sO + qrow_c * LD + 4 * g);
-            const f32x4 s = dot_tile<DS>(qf, kf);
-            const f32x4 dpr = dot_tile<DS>(dof, vf);
-            float pd[4], dsv[4];
+        for (int q4 = 0; q4 < p.n_q; q4 += 16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int q = qt * 16 + 4 * g + r;
-                float dsr = 0.f, pdr = 0.f;
-                if (q < p.n_q && key_ok) {
-                    const float sv = __fadd_rn(__fmul_rn(s[r], p.scale), madd);
-                    const float pv = expf(sv - lse_g[q]);
-                    float d = dpr[r];
-                    pdr = pv;
-                    if (drop) {
-                        const bool keep = vb_keep(p.seed, (uint64_t)((bh * p.n_q + q) * p.n_k + key), p.drop_p);
-                        d = keep ? d * p.drop_scale : 0.f;
-                        pdr = keep ? pv * p.drop_scale : 0.f;
-                    }
-                    dsr = pv * (d - sD[q]) * p.scale;
-                }
-                pd[r] = pdr;
-                dsv[r] = dsr;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qr = min(qt * 16 + 4 * g + r, p.n_q - 1);
+                const int q = q4 + 4 * g + r;
+                const int qr = min(q, p.n_q - 1);
+                // A operands: Pd^T / dS^T element (key = c, q); queries past n_q contribute exactly 0
+                const float pd = q < p.n_q ? sP[qr * LDP + key] : 0.f;
+                const float dsv = q < p.n_q ? sS[qr * LDP + key] : 0.f;
                 const float* dop = sO + qr * LD + c;
                 const float* qp = sQ + qr * LD + c;
                 float dov[DS], qv[DS];
@@ -801,8 +799,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
                 }
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[r], dov[dt], dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[r], qv[dt], dk[dt], 0, 0, 0);
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd, dov[dt], dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv, qv[dt], dk[dt], 0, 0, 0);
                 }
             }
         }
@@ -824,12 +822,16 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
 
 template <int D>
 int launch_bwd_fused_lds(hipStream_t st, const AttnP& p) {
-    const int bytes = ((2 * p.n_k + 2 * p.n_q) * (D + 4) + LDS_MAX_ROWS) * 4;
+    const int ldp = (p.n_k + 3) / 4 * 4 + 4;
+    const int base = (2 * p.n_k + 2 * p.n_q) * (D + 4) + LDS_MAX_ROWS;       // K | V | Q | dO | D vector (floats)
+    const bool over_v = 2 * p.n_q * ldp <= p.n_k * (D + 4);                   // Pd | dS fit over the dead V block
+    const int ps_off = over_v ? p.n_k * (D + 4) : base;
+    const int bytes = (over_v ? base : base + 2 * p.n_q * ldp) * 4;
     // up to 4 x 48 x 132 floats = 101 KiB at head_dim 128: above the 64 KiB a kernel gets by default
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_lds_kernel<D>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL((attn_bwd_fused_lds_kernel<D>), dim3((unsigned)(p.batch * p.heads)), dim3(256), bytes, st, p);
+    hipLaunchKernelGGL((attn_bwd_fused_lds_kernel<D>), dim3((unsigned)(p.batch * p.heads)), dim3(256), bytes, st, p, ps_off);
     VB_LAUNCH_CHECK();
     return 0;
 }
