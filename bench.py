@@ -25,6 +25,10 @@ for p in (os.path.join(ROOT, "vilbert-multi-task_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# streams of the two-stream encoder + RCCL's own streams must not share hardware queues (see vilbert/__init__.py);
+# read by the HIP runtime at its first call, so it has to be in the environment before torch touches the device
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
