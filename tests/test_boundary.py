@@ -74,6 +74,14 @@ def test_head_divisibility_errors():
         _build("vltasks", synth.tiny_config(bi_hidden_size=65))
 
 
+def test_unsupported_head_size_is_reported_at_construction():
+    """Head sizes outside the compiled set {32, 64, 128} are refused when the model is built, not inside a forward."""
+    with pytest.raises(NotImplementedError, match="head size"):
+        _build("vltasks", synth.tiny_config(num_attention_heads=4))          # 64 / 4 = 16
+    with pytest.raises(NotImplementedError, match="head size"):
+        _build("vltasks", synth.tiny_config(v_hidden_size=96, v_num_attention_heads=2))   # 48
+
+
 def test_weight_tying_and_init():
     m = _build("pretraining", synth.tiny_config())
     assert m.cls.predictions.decoder.weight is m.bert.embeddings.word_embeddings.weight

@@ -110,12 +110,13 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def _concurrent(side_fn, main_fn, side_inputs):
+def _concurrent(side_fn, main_fn, side_inputs, enabled=True):
     """Run side_fn() on the side stream and main_fn() on the current stream, join, return both results.
     side_inputs: tensors (allocated on the current stream) the side work reads. Falls back to sequential
     execution (side first) when two-stream mode is off, on CPU tensors, or while a graph is being captured."""
     t0 = side_inputs[0]
-    if not (_TWO_STREAMS and t0.is_cuda) or (torch.cuda.is_current_stream_capturing() and not _TWO_STREAMS_IN_GRAPH):
+    if not (enabled and _TWO_STREAMS and t0.is_cuda) or \
+            (torch.cuda.is_current_stream_capturing() and not _TWO_STREAMS_IN_GRAPH):
         return side_fn(), main_fn()
     main = torch.cuda.current_stream(t0.device)
     side = _side_stream(t0.device)
@@ -130,6 +131,14 @@ def _concurrent(side_fn, main_fn, side_inputs):
         if torch.is_tensor(t):
             t.record_stream(main)   # allocated on `side`, consumed from here on by kernels on `main`
     return a, b
+
+
+def _check_head_dim(d, what):
+    """The native attention kernels are compiled for head dimensions 32, 64 and 128 (every shipped config: 64 / 128)
+    and sequences up to 320 keys; say so at construction time instead of failing inside the first forward."""
+    if d not in (32, 64, 128):
+        raise NotImplementedError("%s: attention head size %d - the native attention kernels are compiled for "
+                                  "head sizes 32, 64 and 128" % (what, d))
 
 
 def _act_name(act):
@@ -235,6 +244,7 @@ class BertSelfAttention(nn.Module):
                              "heads (%d)" % (config.hidden_size, config.num_attention_heads))
         self.num_attention_heads = config.num_attention_heads
         self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        _check_head_dim(self.attention_head_size, "BertSelfAttention")
         self.all_head_size = self.num_attention_heads * self.attention_head_size
         self.visualization = config.visualization
         self.query = nn.Linear(config.hidden_size, self.all_head_size)
@@ -336,6 +346,7 @@ class BertImageSelfAttention(nn.Module):
         self.dynamic_attention = config.dynamic_attention
         self.num_attention_heads = config.v_num_attention_heads
         self.attention_head_size = int(config.v_hidden_size / config.v_num_attention_heads)
+        _check_head_dim(self.attention_head_size, "BertImageSelfAttention")
         self.visualization = config.visualization
         self.all_head_size = self.num_attention_heads * self.attention_head_size
         self.query = nn.Linear(config.v_hidden_size, self.all_head_size)
@@ -419,6 +430,7 @@ class BertBiAttention(nn.Module):
         self.visualization = config.visualization
         self.num_attention_heads = config.bi_num_attention_heads
         self.attention_head_size = int(config.bi_hidden_size / config.bi_num_attention_heads)
+        _check_head_dim(self.attention_head_size, "BertBiAttention")
         self.all_head_size = self.num_attention_heads * self.attention_head_size
         self.query1 = nn.Linear(config.v_hidden_size, self.all_head_size)
         self.key1 = nn.Linear(config.v_hidden_size, self.all_head_size)
@@ -571,8 +583,10 @@ class BertEncoder(nn.Module):
 
             if t_end > t_start and v_end > v_start and not dynamic:
                 # independent stretches of the two streams: image layers on the side stream
+                # (attention maps collected by the layers would escape the side stream: one stream then)
                 image_embedding, txt_embedding = _concurrent(image_part, text_part,
-                                                             [image_embedding, image_attention_mask])
+                                                             [image_embedding, image_attention_mask],
+                                                             enabled=not output_all_attention_masks)
             else:   # (dynamic attention makes the image layers read the UPDATED text stream, :577-586)
                 txt_embedding = text_part()
                 image_embedding = image_part()
@@ -616,7 +630,8 @@ class BertEncoder(nn.Module):
         if len(self.v_layer) > v_start and len(self.layer) > t_start and not dynamic:
             image_embedding, txt_embedding = _concurrent(
                 lambda: run_image(v_start, len(self.v_layer), image_embedding),
-                lambda: run_text(t_start, len(self.layer), txt_embedding), [image_embedding, image_attention_mask])
+                lambda: run_text(t_start, len(self.layer), txt_embedding), [image_embedding, image_attention_mask],
+                enabled=not output_all_attention_masks)
         else:
             image_embedding = run_image(v_start, len(self.v_layer), image_embedding)
             txt_embedding = run_text(t_start, len(self.layer), txt_embedding)
