@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 7
+#define VB_ABI_VERSION 8
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -156,6 +156,46 @@ typedef struct {
 } vb_linear_bwd_weight_args;
 
 int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_args* a);
+
+/* ---- FP8 forward path (BASELINE.json configs[4]: "fp8 MFMA co-attention path"). Not a reference interface: the
+ * reference's reduced-precision switch is apex fp16 (train_tasks.py:168-171 --fp16, vilbert/optimization.py); on
+ * MI355X the matching hardware path is OCP e4m3 on the block-scaled MFMA. The numerics are defined by
+ * oracle/fp8_oracle.py (row-wise amax scaling, round-to-nearest-even e4m3fn, fp32 accumulation).
+ *
+ * vb_quantize_rows_fp8: q[r][0..K) = e4m3(x[r][k] * (448 / amax_r)), scale[r] = amax_r / 448 (1 for an all-zero
+ * row). K % 4 == 0; ldx in floats, ldq in bytes (% 4 == 0); x 16-byte aligned. Used for activations (one scale per
+ * row = per token / region) and weights (one scale per out-feature; segments of a stacked weight are quantised into
+ * row ranges of one [N][K] buffer). */
+int vb_quantize_rows_fp8(void* stream, int64_t rows, int32_t K, const float* x, int64_t ldx, uint8_t* q, int64_t ldq,
+                         float* scale);
+
+/* nn.Linear forward on quantised operands (the fp8 form of vb_linear_fwd, same epilogues):
+ * C[M][N] = act((A . W^T)[m][n] * a_scale[m] * w_scale[n] + bias[n]), then dropout, then + residual.
+ * A [M][K] and W [N][K] e4m3 bytes (K % 128 == 0, lda / ldw in bytes % 16 == 0, 16-byte aligned). preact / act_grad
+ * (may be NULL, at most one of them): receive the pre-activation / act'(pre-activation) as in vb_linear_args. */
+typedef struct {
+    const uint8_t* A;
+    int64_t lda;
+    const float* a_scale;
+    const uint8_t* W;
+    int64_t ldw;
+    const float* w_scale;
+    const float* bias;       /* [N] or NULL */
+    float* C;
+    int64_t ldc;
+    const float* residual;   /* [M][N] or NULL */
+    int64_t ldr;
+    float* preact;           /* [M][N] or NULL: receives the pre-activation (exclusive with act_grad) */
+    int64_t ldp;
+    float* act_grad;
+    int64_t ldg;
+    int32_t M, N, K;
+    int32_t act;             /* VB_ACT_* */
+    float dropout_p;
+    uint64_t seed;
+} vb_linear_fp8_args;
+
+int vb_linear_fwd_fp8(void* stream, const vb_linear_fp8_args* a);
 
 /* dx = dy * act'(preact) elementwise (n % 4 == 0), act in {VB_ACT_GELU, VB_ACT_RELU}: the backward of
  * the GEMM epilogue activation (gelu vilbert.py:111-117, ReLU :1114,1129). */

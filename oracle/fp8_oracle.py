@@ -1,0 +1,74 @@
+"""CPU statement of the FP8 forward path's numerics (TEST INFRASTRUCTURE ONLY - never imported by the product path).
+
+BASELINE.json configs[4] names an "fp8 MFMA co-attention path". The reference has NO fp8 code (its reduced-precision
+switch is apex fp16: /root/reference/train_tasks.py:168-171, vilbert/optimization.py FP16 wrappers), so there is no
+reference behaviour to restate: PARITY UNPINNED against the reference by construction. What this file pins instead:
+
+  * the number format: OCP 8-bit floating point E4M3 ("e4m3fn": 4 exponent bits, bias 7, 3 mantissa bits, no
+    infinities, S.1111.111 = NaN, max finite 448, subnormals m/8 * 2^-6) - restated below from the OCP 8-bit
+    Floating Point Specification (OFP8) rev 1.0, and checked bit-for-bit against PyTorch's independent CPU
+    implementation ``torch.float8_e4m3fn`` over all 256 codes and on random data (tests/test_fp8_oracle.py);
+  * the quantisation recipe of csrc/fp8.hip: one scale per ROW, scale = amax / 448, q = rne(x * (448 / amax));
+  * the product: exact products of the quantised values (every e4m3 x e4m3 product is exact in fp32), summed - here
+    in float64 - and multiplied by the two scales.
+
+The fp8 model-level tolerance (how far an fp8 forward may drift from the fp32 forward) is a measured property stated
+in tests/test_fp8_gpu.py, not a parity claim.
+"""
+import numpy as np
+
+E4M3_MAX = 448.0
+
+
+def e4m3_decode(codes):
+    """uint8 codes -> float32 values (NaN for 0x7f / 0xff)."""
+    c = np.asarray(codes, dtype=np.uint8).astype(np.int32)
+    sign = np.where(c & 0x80, -1.0, 1.0)
+    e = (c >> 3) & 0xF
+    m = c & 0x7
+    val = np.where(e == 0, (m / 8.0) * 2.0 ** -6, (1.0 + m / 8.0) * np.exp2(e.astype(np.float64) - 7.0))
+    val = np.where((e == 15) & (m == 7), np.nan, val)
+    return (sign * val).astype(np.float32)
+
+
+def e4m3_encode(x):
+    """float32 -> uint8 codes, round-to-nearest-even, saturating at +-448 (inputs of the recipe never exceed it)."""
+    x = np.asarray(x, dtype=np.float32)
+    a = np.abs(x).astype(np.float64)
+    sign = (np.signbit(x)).astype(np.int32) << 7
+    a = np.minimum(a, E4M3_MAX)
+    # exponent of the binade (clamped to the subnormal binade -6), quantum = 2^(e - 3)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0))).astype(np.int32)
+    e = np.clip(e, -6, 8)
+    q = np.rint(a / np.exp2(e.astype(np.float64) - 3.0)).astype(np.int32)   # np.rint = ties to even; 0..16
+    carry = q >= 16                                                       # rounded up into the next binade
+    e = np.where(carry, e + 1, e)
+    q = np.where(carry, 8, q)
+    # q < 8 only in the subnormal binade (e == -6): code = q; otherwise (e + 7) << 3 | (q - 8)
+    code = np.where(q < 8, q, ((e + 7) << 3) | (q - 8))
+    code = np.minimum(code, 0x7E)                                         # saturate (448 = 0x7e)
+    return (sign | code).astype(np.uint8)
+
+
+def quantize_rows(x):
+    """x [rows, K] float32 -> (codes uint8 [rows, K], scale float32 [rows]) exactly as quant_rows_kernel."""
+    x = np.asarray(x, dtype=np.float32)
+    amax = np.max(np.abs(x), axis=1).astype(np.float32)
+    zero = ~(amax > 0)
+    safe = np.where(zero, np.float32(1), amax).astype(np.float32)
+    inv = np.where(zero, np.float32(1), np.float32(E4M3_MAX) / safe).astype(np.float32)      # fp32 division
+    scale = np.where(zero, np.float32(1), safe / np.float32(E4M3_MAX)).astype(np.float32)
+    y = (x * inv[:, None]).astype(np.float32)                                                # fp32 multiply
+    return e4m3_encode(y), scale
+
+
+def linear_fp8(x, w, bias=None):
+    """Reference result of vb_linear_fwd_fp8 before the activation: float64 [M, N]."""
+    qa, sa = quantize_rows(x)
+    qw, sw = quantize_rows(w)
+    prod = e4m3_decode(qa).astype(np.float64) @ e4m3_decode(qw).astype(np.float64).T
+    y = prod * sa.astype(np.float64)[:, None] * sw.astype(np.float64)[None, :]
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=np.float64)[None, :]
+    return y

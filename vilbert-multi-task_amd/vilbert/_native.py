@@ -38,6 +38,25 @@ class LinearArgs(ctypes.Structure):
     ]
 
 
+class LinearFp8Args(ctypes.Structure):
+    """vb_linear_fp8_args"""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_int64),
+        ("a_scale", _c_f32p),
+        ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+        ("w_scale", _c_f32p),
+        ("bias", _c_f32p),
+        ("C", _c_f32p), ("ldc", ctypes.c_int64),
+        ("residual", _c_f32p), ("ldr", ctypes.c_int64),
+        ("preact", _c_f32p), ("ldp", ctypes.c_int64),
+        ("act_grad", _c_f32p), ("ldg", ctypes.c_int64),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("act", ctypes.c_int32),
+        ("dropout_p", ctypes.c_float),
+        ("seed", ctypes.c_uint64),
+    ]
+
+
 class AttentionArgs(ctypes.Structure):
     """vb_attention_args"""
     _fields_ = [
@@ -131,6 +150,8 @@ SIGNATURES = {
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
     "vb_linear_bwd_input": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdInputArgs)]),
     "vb_linear_bwd_weight": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdWeightArgs)]),
+    "vb_quantize_rows_fp8": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P]),
+    "vb_linear_fwd_fp8": (ctypes.c_int, [_P, ctypes.POINTER(LinearFp8Args)]),
     "vb_act_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "vb_dropout": (ctypes.c_int, [_P, _I64, _P, _P, _P, _F32, _U64]),
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
@@ -166,9 +187,11 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 7:
+        if handle.vb_abi_version() != 8:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
+        if os.environ.get("VB_GEMM_MODE") == "fp8":
+            _FP8["on"] = True
     return _lib
 
 
@@ -179,12 +202,31 @@ def set_gemm_tile(code):
 
 
 GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
+_FP8 = {"on": False}
 
 
 def set_gemm_mode(mode):
-    """Select the GEMM arithmetic ("f32" exact-fp32 MFMA | "bf16x6" | "bf16x3" | "bf16"); returns the previous name."""
-    prev = lib().vb_set_gemm_mode(GEMM_MODES[mode])
-    return {v: k for k, v in GEMM_MODES.items()}[prev]
+    """Select the GEMM arithmetic; returns the previous name.
+    "f32" exact-fp32 MFMA | "bf16x6" | "bf16x3" | "bf16": arithmetic of every vb_linear_* launch (C side);
+    "fp8": FORWARD linears whose shape allows it run on quantised e4m3 operands (vb_linear_fwd_fp8, host-side weight
+    cache in ops.py); everything else - backward GEMMs, ineligible shapes - stays exact fp32."""
+    prev_fp8 = _FP8["on"]
+    _FP8["on"] = mode == "fp8"
+    prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode == "fp8" else mode])
+    return "fp8" if prev_fp8 else {v: k for k, v in GEMM_MODES.items()}[prev]
+
+
+def fp8_enabled():
+    return _FP8["on"]
+
+
+# Parameters are rewritten through raw pointers by the native optimizer, behind torch's version counters; caches of
+# derived weights (the fp8 codes in ops.py) compare this counter.
+WEIGHTS_EPOCH = [0]
+
+
+def weights_changed():
+    WEIGHTS_EPOCH[0] += 1
 
 
 def check(code, what):

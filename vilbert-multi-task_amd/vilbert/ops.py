@@ -4,6 +4,7 @@ Every function here validates its tensors, allocates the outputs with ``torch.em
 and enqueues exactly the kernels of include/vilbert_hip.h on the current stream. No torch arithmetic.
 """
 import ctypes
+import weakref
 import math
 
 import torch
@@ -79,6 +80,102 @@ def _row_strided(t):
     return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# FP8 forward path (BASELINE config 5; numerics: oracle/fp8_oracle.py, kernels: csrc/fp8.hip)
+# ---------------------------------------------------------------------------------------------------------------
+FP8_K_MULTIPLE = 128     # the fp8 kernel's K step
+_FP8_WEIGHTS = {}        # (data_ptr of every segment) -> (versions, weights epoch, codes [N, K] u8, scales [N], bias [N])
+_WEIGHTS_EPOCH = N.WEIGHTS_EPOCH   # bumped by the native optimizer (parameters rewritten behind torch's version counters)
+
+
+def quantize_rows_fp8(x2, out=None, scale_out=None):
+    """x2 [rows, K] fp32 (row stride allowed) -> (codes [rows, K] uint8, scale [rows] fp32); one scale per row."""
+    rows, K = x2.shape
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    q = out if out is not None else torch.empty((rows, K), dtype=torch.uint8, device=x2.device)
+    sc = scale_out if scale_out is not None else torch.empty((rows,), dtype=torch.float32, device=x2.device)
+    N.check(N.lib().vb_quantize_rows_fp8(N.stream_ptr(), rows, K, N.dev_f32(x2, "fp8 quantise input"), x2.stride(0),
+                                         q.data_ptr(), q.stride(0), sc.data_ptr()), "vb_quantize_rows_fp8")
+    return q, sc
+
+
+def fp8_cache_clear():
+    _FP8_WEIGHTS.clear()
+
+
+def _fp8_sweep():
+    """Drop the entries whose weights nobody else holds any more (their model was deleted)."""
+    dead = [k for k, e in _FP8_WEIGHTS.items() if all(r() is None for r in e[6])]
+    for k in dead:
+        del _FP8_WEIGHTS[k]
+
+
+def _fp8_weights(weights, biases):
+    """Quantised copy of the (stacked) weight, cached until a segment is rewritten. The entry keeps an alias of every
+    segment alive, so a key (the segments' addresses) can never be recycled by a different tensor while it is cached;
+    entries whose weight tensors (the nn.Parameter objects the callers pass) are gone are dropped at the next miss."""
+    key = tuple(w.data_ptr() for w in weights)
+    vers = tuple(w._version for w in weights) + tuple(-1 if b is None else b._version for b in (biases or []))
+    seg_n, K = weights[0].shape
+    n = seg_n * len(weights)
+    hit = _FP8_WEIGHTS.get(key)
+    if hit is not None and hit[2].shape != (n, K):
+        hit = None                                  # same address, different view of a buffer
+    if hit is not None and hit[0] == vers and hit[1] == _WEIGHTS_EPOCH[0]:
+        return hit[2], hit[3], hit[4]
+    dev = weights[0].device
+    if hit is not None:
+        q, sc, bias = hit[2], hit[3], hit[4]        # refresh in place: same addresses (HIP graphs keep them)
+    else:
+        _fp8_sweep()
+        q = torch.empty((n, K), dtype=torch.uint8, device=dev)
+        sc = torch.empty((n,), dtype=torch.float32, device=dev)
+        bias = None
+    with torch.no_grad():
+        for s, w in enumerate(weights):
+            quantize_rows_fp8(w.detach(), q[s * seg_n:(s + 1) * seg_n], sc[s * seg_n:(s + 1) * seg_n])
+        if biases is not None and all(b is not None for b in biases):
+            cat = biases[0].detach() if len(biases) == 1 else torch.cat([b.detach() for b in biases])
+            if bias is None or len(biases) == 1:
+                bias = cat
+            else:
+                bias.copy_(cat)
+        elif biases is not None and any(b is not None for b in biases):
+            raise RuntimeError("linear (fp8): either every weight segment has a bias or none")
+        else:
+            bias = None
+    _FP8_WEIGHTS[key] = (vers, _WEIGHTS_EPOCH[0], q, sc, bias, [w.detach() for w in weights],
+                         [weakref.ref(w) for w in weights])
+    return q, sc, bias
+
+
+def _fp8_eligible(x2, K, n_out):
+    # K a multiple of the kernel's K step; tiny heads (N < 64) and ragged K stay exact fp32
+    return K % FP8_K_MULTIPLE == 0 and n_out >= 64 and x2.is_cuda
+
+
+def _linear_fwd_fp8(x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed):
+    wq, ws, bias = _fp8_weights(weights, biases)
+    xq, xs = quantize_rows_fp8(x2)
+    a = N.LinearFp8Args()
+    a.A, a.lda, a.a_scale = xq.data_ptr(), K, xs.data_ptr()
+    a.W, a.ldw, a.w_scale = wq.data_ptr(), K, ws.data_ptr()
+    a.bias = N.dev_f32(bias, "linear bias") if bias is not None else None
+    a.C, a.ldc = y.data_ptr(), ldc
+    if residual is not None:
+        a.residual, a.ldr = N.dev_f32(residual, "linear residual"), n_out
+    if pre is not None and want_act_grad:
+        a.act_grad, a.ldg = pre.data_ptr(), n_out
+    elif pre is not None:
+        a.preact, a.ldp = pre.data_ptr(), n_out
+    a.M, a.N, a.K = M, n_out, K
+    a.act = N.ACT_CODES[act]
+    a.dropout_p, a.seed = float(drop_p), int(seed)
+    _timed(lambda: N.check(N.lib().vb_linear_fwd_fp8(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd_fp8"),
+           2.0 * M * n_out * K, ("fwd_fp8", M, n_out, K, 1))
+
+
 def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0,
                want_act_grad=False, pad_cols=False):
     """act(x @ cat(weights).T + cat(biases)) (+ residual).
@@ -110,6 +207,16 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     else:
         y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if (want_preact or want_act_grad) else None
+    if N.fp8_enabled() and _fp8_eligible(x2, K, n_out):
+        for w in weights:
+            if w.shape != (seg_n, K) or not w.is_contiguous():
+                raise RuntimeError("linear: weight segments must be contiguous and equally shaped")
+        if residual is not None:
+            residual = _contig(residual)
+            if residual.numel() != M * n_out:
+                raise RuntimeError("linear: residual shape mismatch")
+        _linear_fwd_fp8(x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed)
+        return y, pre
     a = N.LinearArgs()
     a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
     a.A, a.lda = N.dev_f32(x2, "linear input"), lda

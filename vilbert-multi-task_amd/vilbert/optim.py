@@ -131,6 +131,7 @@ class AdamW(Optimizer):
         N.check(N.lib().vb_adamw_step(N.stream_ptr(), plan["n_chunks"], dev_tab.data_ptr(),
                                       plan["chunk_tensor"].data_ptr(), plan["chunk_off"].data_ptr(), CHUNK_ELEMS),
                 "vb_adamw_step")
+        N.weights_changed()
         del keep
         return loss
 
