@@ -38,9 +38,11 @@ __device__ __forceinline__ float gelu_fast(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Row quantiser: one wave per row, 4 rows per block. Two sweeps over the row (the second one hits L2 / MALL: a row is
-// at most 16 KB): amax, then scale + convert 4 values -> 4 bytes per lane and sweep (256 B per wave store).
+// Row quantiser: one wave per row, 4 rows per block. NV > 0: the row (K = 256 NV floats, the widths of the encoder:
+// 768, 1024, 2048, 3072, 4096) is read ONCE into NV float4 registers per lane - amax, scale, convert, 256-byte stores.
+// NV == 0: any K % 4 == 0 in two sweeps (the second one hits L2: a row is at most 16 KB).
 // ---------------------------------------------------------------------------------------------------------------
+template <int NV>
 __global__ __launch_bounds__(256) void quant_rows_kernel(long rows, int K, const float* __restrict__ x, long ldx,
                                                          unsigned char* __restrict__ q, long ldq,
                                                          float* __restrict__ scale) {
@@ -48,23 +50,36 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(long rows, int K, const
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(x + row * ldx);
+    unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(q + row * ldq);
     const int nv = K >> 2;
+    f32x4 reg[NV > 0 ? NV : 1];
     float amax = 0.f;
-    for (int i = lane; i < nv; i += 64) {
-        const f32x4 v = src[i];
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reg[i] = src[lane + 64 * i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(reg[i][0]), fabsf(reg[i][1])), fmaxf(fabsf(reg[i][2]), fabsf(reg[i][3]))));
+    } else {
+        for (int i = lane; i < nv; i += 64) {
+            const f32x4 v = src[i];
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
     const bool zero = !(amax > 0.f);
     const float inv = zero ? 1.f : E4M3_MAX / amax;
     if (lane == 0) scale[row] = zero ? 1.f : amax / E4M3_MAX;
-    unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(q + row * ldq);
-    for (int i = lane; i < nv; i += 64) {
-        const f32x4 v = src[i];
+    auto pack = [&](const f32x4 v) {
         int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, 0, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w, true);
-        dst[i] = (unsigned)w;
+        return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w, true);
+    };
+    if (NV > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) dst[lane + 64 * i] = pack(reg[i]);
+    } else {
+        for (int i = lane; i < nv; i += 64) dst[i] = pack(src[i]);
     }
 }
 
@@ -261,8 +276,18 @@ extern "C" int vb_quantize_rows_fp8(void* stream, int64_t rows, int32_t K, const
     if (K % 4 != 0 || ldx % 4 != 0 || ldq % 4 != 0 || ldq < K || ldx < K || !vb_aligned16(x) ||
         (reinterpret_cast<uintptr_t>(q) & 3u) != 0)
         return VB_E_ALIGN;
-    hipLaunchKernelGGL(quant_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       rows, K, x, ldx, q, ldq, scale);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define VB_QUANT(NV) hipLaunchKernelGGL(quant_rows_kernel<NV>, grid, block, 0, st, rows, K, x, ldx, q, ldq, scale)
+    switch (K) {
+        case 768: VB_QUANT(3); break;
+        case 1024: VB_QUANT(4); break;
+        case 2048: VB_QUANT(8); break;
+        case 3072: VB_QUANT(12); break;
+        case 4096: VB_QUANT(16); break;
+        default: VB_QUANT(0); break;
+    }
+#undef VB_QUANT
     VB_LAUNCH_CHECK();
     return 0;
 }
