@@ -225,13 +225,18 @@ def main():
             raise SystemExit("--global-batch must be divisible by the number of ranks")
         B = args.global_batch // world
 
-    def forward_workload(batch):
-        """(step, inputs dict, model): VILBertForVLTasks forward, eval + no_grad."""
+    def forward_workload(batch, graph=False):
+        """(step, inputs dict, model): VILBertForVLTasks forward, eval + no_grad (graph: replayed as one HIP graph)."""
         xb = synthetic_batch(cfg, batch, N_TOK, N_REG, 7 + rank, False)
         names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
                  "image_attention_mask", "co_attention_mask"]
         inp = tuple(xb[n].to(device) for n in names)
         net = build_model(cfg, "vltasks", device).eval()
+
+        if graph:
+            from vilbert.graphed import GraphedForward
+            gf = GraphedForward(net, inp)
+            return (lambda: gf(*inp)), xb, net
 
         def fstep():
             with torch.no_grad():
@@ -365,11 +370,17 @@ def main():
                                              "e4m3 operands (row-wise scales, v_mfma_scale_f32_32x32x64_f8f6f4, fp32 "
                                              "accumulate); attention / LayerNorm / heads with N < 64 stay fp32"}
             f128, _, _ = forward_workload(128)
-            f128_dt = timed(f128, 2, n_f)
-            extra["fwd_fp8_b128"] = {"value": round(128 * n_f / f128_dt, 2), "unit": "samples/s",
-                                     "ms_per_step": round(1e3 * f128_dt / n_f, 3), "steps": n_f,
-                                     "note": "per-GPU share of BASELINE configs[4] (batch 1024 over 8 GPUs = 128 per GPU)"}
-            del f128
+            n128 = 4 * n_f
+            f128_dt = timed(f128, 2, n128)
+            g128, _, _ = forward_workload(128, graph=True)
+            g128_dt = timed(g128, 2, n128)
+            extra["fwd_fp8_b128"] = {"value": round(128 * n128 / min(f128_dt, g128_dt), 2), "unit": "samples/s",
+                                     "eager": round(128 * n128 / f128_dt, 2), "graphed": round(128 * n128 / g128_dt, 2),
+                                     "ms_per_step": round(1e3 * min(f128_dt, g128_dt) / n128, 3), "steps": n128,
+                                     "note": "per-GPU share of BASELINE configs[4] (batch 1024 over 8 GPUs = 128 per GPU): "
+                                             "eager launches vs the forward replayed as one HIP graph "
+                                             "(vilbert/graphed.py GraphedForward)"}
+            del f128, g128
         finally:
             _native.set_gemm_mode("f32")
         del fstep, fmodel
@@ -385,7 +396,9 @@ def main():
                  "bf16": "opt-in reduced-precision mode (BASELINE configs[4] direction): operands rounded to bf16, one "
                          "MFMA product, fp32 accumulate, fp32 tensors in HBM; NOT inside the 1e-4 parity bar (measured "
                          "error ~1e-2 of the output range, tests/test_gemm_modes_gpu.py); bf16 MFMA peak 2500 TF"}
-        for mode in ("bf16x6", "bf16"):
+        notes["fp8"] = "opt-in: FORWARD linears on OCP e4m3 operands (csrc/fp8.hip), backward GEMMs exact fp32 on the saved " \
+                       "fp32 activations (straight-through); outside the 1e-4 parity bar (tests/test_fp8_gpu.py)"
+        for mode in ("bf16x6", "bf16", "fp8"):
             _native.set_gemm_mode(mode)
             for _ in range(2):
                 step()

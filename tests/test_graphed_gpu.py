@@ -137,3 +137,33 @@ def test_graphed_step_draws_fresh_dropout_masks_every_replay():
     losses = [step(*args).item() for _ in range(4)]
     step.close()
     assert all(l == l for l in losses) and len(set(losses)) == 4
+
+
+@pytest.mark.parametrize("mode", ["f32", "fp8"])
+def test_graphed_forward_matches_eager(mode):
+    """Inference forward replayed as one HIP graph: same outputs as the eager forward, also after new inputs."""
+    from oracle import synth
+    from vilbert import _native
+    from vilbert.graphed import GraphedForward
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    m = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    m.load_state_dict(synth.make_state_dict(cfg, "vltasks"))
+    m = m.eval().to(DEV)
+    names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+             "co_attention_mask"]
+    xs = [synth.make_inputs(cfg, 6, 20, 36, seed=s) for s in (1, 2)]
+    ins = [tuple(x[n].to(DEV) for n in names) for x in xs]
+    prev = _native.set_gemm_mode(mode)
+    try:
+        gf = GraphedForward(m, ins[0])
+        for inp in (ins[0], ins[1], ins[0]):
+            got = [o.clone() for o in gf(*inp) if torch.is_tensor(o)]
+            with torch.no_grad():
+                want = [o for o in m(*inp) if torch.is_tensor(o)]
+            assert len(got) == len(want) and len(got) >= 8
+            for a, b in zip(got, want):
+                assert a.shape == b.shape
+                assert torch.equal(a, b) or (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item())
+    finally:
+        _native.set_gemm_mode(prev)

@@ -115,3 +115,41 @@ class GraphedTrainStep(object):
         N.check(N.lib().vb_set_seed_epoch(None), "vb_set_seed_epoch")
         if hasattr(self._base, "label_capacity"):
             self._base.label_capacity = None
+
+
+class GraphedForward(object):
+    """Inference forward (eval, no_grad) as ONE HIP graph launch: at the per-GPU batch of BASELINE configs[4]
+    (1024 / 8 = 128 samples, fp8 linears) the ~450 launches of a forward take ~6.6 ms to issue against ~4 ms of GPU work.
+    ``fwd = GraphedForward(model, example_inputs); out = fwd(*batch)`` - the outputs are static tensors, overwritten by
+    the next call. In fp8 mode the quantised weights are taken from the cache that the warm-up filled, so the graph
+    contains no weight quantisation (call again after the weights change)."""
+
+    def __init__(self, model, example_inputs, warmup=2):
+        dev = example_inputs[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedForward needs HIP-device inputs - no CPU fallback")
+        if model.training:
+            raise RuntimeError("GraphedForward captures an inference forward: call model.eval() first")
+        self.model = model
+        self.static = [t.clone() if torch.is_tensor(t) else t for t in example_inputs]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model(*self.static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = model(*self.static)
+
+    def __call__(self, *inputs):
+        if len(inputs) != len(self.static):
+            raise RuntimeError("GraphedForward: expected %d inputs" % len(self.static))
+        for s, t in zip(self.static, inputs):
+            if torch.is_tensor(s) and s.data_ptr() != t.data_ptr():
+                if s.shape != t.shape or s.dtype != t.dtype:
+                    raise RuntimeError("GraphedForward: input shape / dtype differs from the captured one")
+                s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.out
