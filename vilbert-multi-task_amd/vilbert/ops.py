@@ -150,9 +150,11 @@ def _fp8_weights(weights, biases):
     return q, sc, bias
 
 
-def _fp8_eligible(x2, K, n_out):
-    # K a multiple of the kernel's K step; tiny heads (N < 64) and ragged K stay exact fp32
-    return K % FP8_K_MULTIPLE == 0 and n_out >= 64 and x2.is_cuda
+def _fp8_eligible(x2, K, n_out, biases):
+    # K a multiple of the kernel's K step; tiny heads (N < 64), ragged K and stacked weights of which only some
+    # segments have a bias stay exact fp32
+    uniform_bias = biases is None or all(b is None for b in biases) or all(b is not None for b in biases)
+    return K % FP8_K_MULTIPLE == 0 and n_out >= 64 and x2.is_cuda and uniform_bias
 
 
 def _linear_fwd_fp8(x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed):
@@ -207,7 +209,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     else:
         y = torch.empty(lead + (n_out,), dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if (want_preact or want_act_grad) else None
-    if N.fp8_enabled() and _fp8_eligible(x2, K, n_out):
+    if N.fp8_enabled() and _fp8_eligible(x2, K, n_out, biases):
         for w in weights:
             if w.shape != (seg_n, K) or not w.is_contiguous():
                 raise RuntimeError("linear: weight segments must be contiguous and equally shaped")
