@@ -23,20 +23,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr float E4M3_MAX = 448.0f;
 
-// GELU for the fp8 epilogue: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp8 operand noise),
-// ~16 VALU instructions with one v_rcp and one v_exp. The libdevice erff of the fp32 kernels costs ~40: at fp8 GEMM
-// speed that was 58 us of VALU in a 160 us FFN GEMM (18432 x 3072 outputs).
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float z = fabsf(v) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erf_abs = 1.0f - poly * t * __expf(-z * z);
-    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Row quantiser: one wave per row, 4 rows per block. NV > 0: the row (K = 256 NV floats, the widths of the encoder:
 // 768, 1024, 2048, 3072, 4096) is read ONCE into NV float4 registers per lane - amax, scale, convert, 256-byte stores.
@@ -259,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const GemmP p, const F
                     if (p.drop_p > 0.f)
                         v = vb_keep(seed, (uint64_t)((long)row * p.N + col), p.drop_p) ? v * p.drop_scale : 0.f;
                 }
-                if (MODE == 2) v = gelu_fast(v);
+                if (MODE == 2) v = gelu_erf(v);
                 if (has_r) v += rv[j][r];
                 if (inside && (x.abl != 1 || v == 12345.678f)) p.C[0][(long)row * p.ldc + col] = v;
             }

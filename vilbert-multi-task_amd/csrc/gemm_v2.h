@@ -83,7 +83,7 @@ __device__ __forceinline__ void epilogue_v2(const GemmP& p, float* __restrict__ 
                 // backward then needs one multiply in a dgrad epilogue - no erf / exp, no separate pass)
                 f32x4 d;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { d[e] = gelu_grad(v[e]); v[e] = gelu_erf(v[e]); }
+                for (int e = 0; e < 4; ++e) { float y, dd; gelu_and_grad(v[e], y, dd); v[e] = y; d[e] = dd; }
                 *reinterpret_cast<f32x4*>(p.D + (long)row * p.ldd + col) = d;
             } else if (MODE == EPI_GELU) {
 #pragma unroll
