@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 8
+#define VB_ABI_VERSION 9
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -196,6 +196,14 @@ typedef struct {
 } vb_linear_fp8_args;
 
 int vb_linear_fwd_fp8(void* stream, const vb_linear_fp8_args* a);
+
+/* BertLayerNorm forward (vilbert.py:313-317, as vb_layernorm_fwd: y = LN(x (+ x2))) that ALSO emits the e4m3 codes and
+ * scale of every output row for the fp8 linears consuming it (inference in fp8 mode): q[r][0..n_cols), row stride ldq
+ * bytes (% 4 == 0), qscale[rows]. Bit-identical to vb_layernorm_fwd followed by vb_quantize_rows_fp8 on y - it saves
+ * that second pass (one read of the row). */
+int vb_layernorm_fwd_fp8(void* stream, int64_t rows, int32_t n_cols, const float* x, const float* x2,
+                         const float* gamma, const float* beta, float eps, float* y, uint8_t* q, int64_t ldq,
+                         float* qscale);
 
 /* dx = dy * act'(preact) elementwise (n % 4 == 0), act in {VB_ACT_GELU, VB_ACT_RELU}: the backward of
  * the GEMM epilogue activation (gelu vilbert.py:111-117, ReLU :1114,1129). */

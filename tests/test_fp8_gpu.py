@@ -175,6 +175,42 @@ def test_fp8_weight_cache_follows_updates(fp8_mode):
     assert w._version >= v0
 
 
+@pytest.mark.parametrize("rows,cols,with_x2", [(37, 768, False), (130, 1024, True), (5, 2048, False)])
+def test_layernorm_emits_the_same_codes_as_the_quantiser(fp8_mode, rows, cols, with_x2):
+    """Inference in fp8 mode: the LayerNorm kernel's fused e4m3 output is bit-identical to quantising its fp32 output,
+    the fp32 output is bit-identical to the plain LayerNorm, and the consuming linear really uses the fused codes."""
+    from vilbert import _native, ops
+    x = _rand(rows, cols, seed=1).to(DEV) * 3
+    x2 = _rand(rows, cols, seed=2).to(DEV) if with_x2 else None
+    g, b = (1 + 0.1 * _rand(cols, seed=3)).to(DEV), (0.1 * _rand(cols, seed=4)).to(DEV)
+    with torch.no_grad():
+        y, _, _ = ops.layernorm_fwd(x, g, b, 1e-12, x2)
+    assert hasattr(y, "_vb_fp8")
+    q, sc, ver = y._vb_fp8
+    prev = _native.set_gemm_mode("f32")
+    with torch.no_grad():
+        y32, _, _ = ops.layernorm_fwd(x, g, b, 1e-12, x2)
+    _native.set_gemm_mode(prev)
+    assert torch.equal(y, y32) and not hasattr(y32, "_vb_fp8")
+    q_ref, s_ref = F.quantize_rows(y.cpu().numpy())
+    assert np.array_equal(q.cpu().numpy(), q_ref) and np.array_equal(sc.cpu().numpy(), s_ref)
+    # the consumer takes the fused codes: poison them and the result must change; restore -> equals the separate path
+    w = _rand(128, cols, seed=5, scale=0.05).to(DEV)
+    with torch.no_grad():
+        out_fused, _ = ops.linear_fwd(y, [w], None)
+        out_sep, _ = ops.linear_fwd(y.clone(), [w], None)          # a different object: quantised by the linear itself
+        assert torch.equal(out_fused, out_sep)
+        q.zero_()
+        out_poison, _ = ops.linear_fwd(y, [w], None)
+        assert out_poison.abs().max().item() == 0.0
+        y.add_(1.0)                                                # modified in place: the stale codes must be ignored
+        out_mod, _ = ops.linear_fwd(y, [w], None)
+        assert out_mod.abs().max().item() > 0.0
+    # under autograd the fused path is not taken
+    y_grad, _, _ = ops.layernorm_fwd(x, g, b, 1e-12, x2, want_stats=True)
+    assert not hasattr(y_grad, "_vb_fp8")
+
+
 def test_fp8_weight_cache_survives_address_reuse(fp8_mode):
     """A new weight allocated at the address of a deleted one must not hit the old entry (regression: the stale codes
     of a different shape sent the GEMM out of bounds)."""

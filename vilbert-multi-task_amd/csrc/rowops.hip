@@ -16,7 +16,8 @@ constexpr int ROWS_PER_BLOCK = 4;  // 4 waves
 template <int NV>
 __device__ __forceinline__ void ln_finish(f32x4 (&x)[NV], int n_cols, int lane, const float* gamma,
                                           const float* beta, float eps, float* yrow, float* mean_out,
-                                          float* rstd_out, float* presum_row = nullptr) {
+                                          float* rstd_out, float* presum_row = nullptr,
+                                          unsigned char* qrow = nullptr, float* qscale = nullptr) {
     if (presum_row != nullptr) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -46,13 +47,35 @@ __device__ __forceinline__ void ln_finish(f32x4 (&x)[NV], int n_cols, int lane, 
         if (mean_out != nullptr) *mean_out = mean;
         if (rstd_out != nullptr) *rstd_out = rstd;
     }
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * 4;
         if (col < n_cols) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
             const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
-            *reinterpret_cast<f32x4*>(yrow + col) = g * (x[i] * rstd) + b;
+            x[i] = g * (x[i] * rstd) + b;
+            *reinterpret_cast<f32x4*>(yrow + col) = x[i];
+            if (qrow != nullptr)
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fmaxf(fabsf(x[i][2]), fabsf(x[i][3]))));
+        }
+    }
+    if (qrow != nullptr) {
+        // the row's e4m3 codes + scale for the fp8 linears that consume it (same recipe, same bits as
+        // vb_quantize_rows_fp8 applied to the stored row - csrc/fp8.hip)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const bool zero = !(amax > 0.f);
+        const float inv = zero ? 1.f : 448.0f / amax;
+        if (lane == 0) *qscale = zero ? 1.f : amax / 448.0f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            if (col < n_cols) {
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(x[i][0] * inv, x[i][1] * inv, 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(x[i][2] * inv, x[i][3] * inv, w, true);
+                *reinterpret_cast<unsigned*>(qrow + col) = (unsigned)w;
+            }
         }
     }
 }
@@ -62,7 +85,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(long rows, int n_cols, c
                                                         const float* __restrict__ x2,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* __restrict__ y, float* mean, float* rstd) {
+                                                        float* __restrict__ y, float* mean, float* rstd,
+                                                        unsigned char* __restrict__ q, long ldq,
+                                                        float* __restrict__ qscale) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -78,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(long rows, int n_cols, c
         }
     }
     ln_finish<NV>(v, n_cols, lane, gamma, beta, eps, y + row * n_cols, mean ? mean + row : nullptr,
-                  rstd ? rstd + row : nullptr);
+                  rstd ? rstd + row : nullptr, nullptr, q ? q + row * ldq : nullptr, q ? qscale + row : nullptr);
 }
 
 // reference vilbert.py:346-367
@@ -213,7 +238,29 @@ extern "C" int vb_layernorm_fwd(void* stream, int64_t rows, int32_t n_cols, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
     VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, (long)rows,
-                                                      n_cols, x, x2, gamma, beta, eps, y, mean, rstd));
+                                                      n_cols, x, x2, gamma, beta, eps, y, mean, rstd,
+                                                      (unsigned char*)nullptr, 0L, (float*)nullptr));
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+// LayerNorm forward that also emits the row's e4m3 codes + scale (inference in fp8 mode: the consumer GEMMs read the
+// codes, the fp32 row stays for the residual path). Bit-identical to vb_layernorm_fwd followed by vb_quantize_rows_fp8.
+extern "C" int vb_layernorm_fwd_fp8(void* stream, int64_t rows, int32_t n_cols, const float* x, const float* x2,
+                                    const float* gamma, const float* beta, float eps, float* y, uint8_t* q,
+                                    int64_t ldq, float* qscale) {
+    if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || q == nullptr || qscale == nullptr ||
+        rows <= 0)
+        return VB_E_BADARG;
+    if (int e = check_cols(n_cols)) return e;
+    if (!vb_aligned16(x) || !vb_aligned16(y) || !vb_aligned16(gamma) || !vb_aligned16(beta) ||
+        (x2 != nullptr && !vb_aligned16(x2)) || ldq < n_cols || ldq % 4 != 0 || (reinterpret_cast<uintptr_t>(q) & 3u) != 0)
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, (long)rows,
+                                                      n_cols, x, x2, gamma, beta, eps, y, (float*)nullptr,
+                                                      (float*)nullptr, q, (long)ldq, qscale));
     VB_LAUNCH_CHECK();
     return 0;
 }

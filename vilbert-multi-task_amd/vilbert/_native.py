@@ -152,6 +152,7 @@ SIGNATURES = {
     "vb_linear_bwd_weight": (ctypes.c_int, [_P, ctypes.POINTER(LinearBwdWeightArgs)]),
     "vb_quantize_rows_fp8": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P]),
     "vb_linear_fwd_fp8": (ctypes.c_int, [_P, ctypes.POINTER(LinearFp8Args)]),
+    "vb_layernorm_fwd_fp8": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P]),
     "vb_act_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "vb_dropout": (ctypes.c_int, [_P, _I64, _P, _P, _P, _F32, _U64]),
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
@@ -187,7 +188,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 8:
+        if handle.vb_abi_version() != 9:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") == "fp8":

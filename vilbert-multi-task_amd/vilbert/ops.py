@@ -157,9 +157,13 @@ def _fp8_eligible(x2, K, n_out, biases):
     return K % FP8_K_MULTIPLE == 0 and n_out >= 64 and x2.is_cuda and uniform_bias
 
 
-def _linear_fwd_fp8(x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed):
+def _linear_fwd_fp8(x, x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed):
     wq, ws, bias = _fp8_weights(weights, biases)
-    xq, xs = quantize_rows_fp8(x2)
+    pre_q = getattr(x, "_vb_fp8", None)     # codes emitted by the producing LayerNorm (layernorm_fwd)
+    if pre_q is not None and pre_q[2] == x._version and pre_q[0].shape == (M, K) and x.is_contiguous():
+        xq, xs = pre_q[0], pre_q[1]
+    else:
+        xq, xs = quantize_rows_fp8(x2)
     a = N.LinearFp8Args()
     a.A, a.lda, a.a_scale = xq.data_ptr(), K, xs.data_ptr()
     a.W, a.ldw, a.w_scale = wq.data_ptr(), K, ws.data_ptr()
@@ -217,7 +221,7 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
             residual = _contig(residual)
             if residual.numel() != M * n_out:
                 raise RuntimeError("linear: residual shape mismatch")
-        _linear_fwd_fp8(x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed)
+        _linear_fwd_fp8(x, x2, M, K, weights, biases, n_out, y, ldc, act, residual, pre, want_act_grad, drop_p, seed)
         return y, pre
     a = N.LinearArgs()
     a.M, a.K, a.nseg, a.seg_n = M, K, nseg, seg_n
@@ -356,6 +360,21 @@ def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
     rows, cols = _rows(x)
     y = torch.empty_like(x)
     mean = rstd = None
+    if N.fp8_enabled() and not want_stats and not torch.is_grad_enabled() and cols % FP8_K_MULTIPLE == 0 and x.is_cuda:
+        # inference in fp8 mode: the LayerNorm kernel also emits the e4m3 codes of its output rows; the linears that
+        # consume this very tensor (same object, not modified since) skip their quantiser pass
+        if x2 is not None:
+            x2 = _contig(x2)
+            if x2.shape != x.shape:
+                raise RuntimeError("layernorm: x2 shape mismatch")
+        q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+        sc = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        N.check(N.lib().vb_layernorm_fwd_fp8(
+            N.stream_ptr(), rows, cols, N.dev_f32(x, "layernorm input"), N.dev_f32(x2, "layernorm x2"),
+            N.dev_f32(gamma, "layernorm weight"), N.dev_f32(beta, "layernorm bias"), eps, y.data_ptr(), q.data_ptr(),
+            cols, sc.data_ptr()), "vb_layernorm_fwd_fp8")
+        y._vb_fp8 = (q, sc, y._version)
+        return y, None, None
     if want_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
