@@ -204,11 +204,14 @@ class SelfAttnFn(Function):
         if probs is None:
             probs = qkv.new_empty(0)
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)      # no zeros() for the gradient slot of the non-differentiable probs
         return out, probs
 
     @staticmethod
     def backward(ctx, d_out, _d_probs):
         qkv, mask_add, lse = ctx.saved_tensors
+        if d_out is None:
+            return None, None, None, None, None
         heads, drop_p, seed = ctx.meta
         H = qkv.shape[-1] // 3
         dqkv = torch.empty_like(qkv)
@@ -236,12 +239,19 @@ class BiAttnFn(Function):
         if probs1 is None:
             probs1, probs2 = qkv1.new_empty(0), qkv1.new_empty(0)
         ctx.mark_non_differentiable(probs1, probs2)
+        ctx.set_materialize_grads(False)
         return ctx1, ctx2, probs1, probs2
 
     @staticmethod
     def backward(ctx, d1, d2, _dp1, _dp2):
         qkv1, qkv2, mask1, mask2, lse1, lse2 = ctx.saved_tensors
         heads, p1, p2, s1, s2 = ctx.meta
+        if d1 is None and d2 is None:
+            return (None,) * 8
+        if d1 is None:                         # only one direction reached the loss: the other one's gradient is zero
+            d1 = torch.zeros((qkv2.shape[0], qkv2.shape[1], qkv1.shape[-1] // 3), dtype=qkv1.dtype, device=qkv1.device)
+        if d2 is None:
+            d2 = torch.zeros((qkv1.shape[0], qkv1.shape[1], qkv1.shape[-1] // 3), dtype=qkv1.dtype, device=qkv1.device)
         H = qkv1.shape[-1] // 3
         sl = lambda t: (t[..., :H], t[..., H:2 * H], t[..., 2 * H:])
         q1, k1, v1 = sl(qkv1)
