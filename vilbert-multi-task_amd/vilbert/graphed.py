@@ -103,6 +103,7 @@ class GraphedTrainStep(object):
                 s.copy_(t, non_blocking=True)
         self.opt.prepare_replay()
         self.graph.replay()
+        N.weights_changed()          # the replayed optimizer kernel rewrote the parameters (caches of derived weights)
         self.replays += 1
         return self.loss
 

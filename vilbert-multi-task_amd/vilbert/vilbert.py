@@ -121,15 +121,20 @@ def _concurrent(side_fn, main_fn, side_inputs, enabled=True):
     main = torch.cuda.current_stream(t0.device)
     side = _side_stream(t0.device)
     side.wait_stream(main)
+    def _record(t, stream):
+        t.record_stream(stream)
+        for extra in getattr(t, "_vb_fp8", ())[:2]:     # e4m3 codes + scales riding on a LayerNorm output (ops.py)
+            extra.record_stream(stream)
+
     for t in side_inputs:
-        t.record_stream(side)       # allocated on `main`, consumed by kernels on `side`
+        _record(t, side)            # allocated on `main`, consumed by kernels on `side`
     with torch.cuda.stream(side):
         a = side_fn()
     b = main_fn()
     main.wait_stream(side)
     for t in (a if isinstance(a, (tuple, list)) else (a,)):
         if torch.is_tensor(t):
-            t.record_stream(main)   # allocated on `side`, consumed from here on by kernels on `main`
+            _record(t, main)        # allocated on `side`, consumed from here on by kernels on `main`
     return a, b
 
 
