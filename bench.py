@@ -398,7 +398,10 @@ def main():
                          "error ~1e-2 of the output range, tests/test_gemm_modes_gpu.py); bf16 MFMA peak 2500 TF"}
         notes["fp8"] = "opt-in: FORWARD linears on OCP e4m3 operands (csrc/fp8.hip), backward GEMMs exact fp32 on the saved " \
                        "fp32 activations (straight-through); outside the 1e-4 parity bar (tests/test_fp8_gpu.py)"
-        for mode in ("bf16x6", "bf16", "fp8"):
+        notes["fp8+bf16"] = "opt-in: fp8 forward linears (as 'fp8') + bf16-operand backward GEMMs (as 'bf16'), fp32 master " \
+                            "weights, accumulation, LayerNorm, attention and optimizer - throughput data point, no " \
+                            "convergence claim"
+        for mode in ("bf16x6", "bf16", "fp8", "fp8+bf16"):
             _native.set_gemm_mode(mode)
             for _ in range(2):
                 step()

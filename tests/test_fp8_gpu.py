@@ -252,3 +252,23 @@ def test_fp8_model_drift_is_bounded_and_reported(fp8_mode, case):
         assert rel <= 0.25 and l2 <= 0.25, "%s/%s: fp8-mode error %.3e of the output range" % (case, n, rel)
     print("fp8 mode, %s: worst output error %.2e of the output range (fp32 mode: < 1e-4)" % (case, worst))
     assert worst > 1e-4       # it really is a different arithmetic
+
+
+def test_fp8_plus_bf16_mode_composes_the_two_modes():
+    """"fp8+bf16": forward = the fp8 forward (bit-identical), backward GEMMs = the bf16 mode's (bit-identical dgrad)."""
+    from vilbert import _native, ops
+    x = _rand(160, 768, seed=1).to(DEV)
+    w = _rand(1024, 768, seed=2, scale=0.03).to(DEV)
+    b = _rand(1024, seed=3).to(DEV)
+    dy = _rand(160, 1024, seed=4).to(DEV)
+    res = {}
+    for mode in ("fp8", "bf16", "fp8+bf16"):
+        prev = _native.set_gemm_mode(mode)
+        try:
+            y, _ = ops.linear_fwd(x, [w], [b], act="gelu")
+            dx = ops.linear_bwd_input(dy, [w], 768)
+            res[mode] = (y, dx)
+        finally:
+            assert _native.set_gemm_mode(prev) == mode
+    assert torch.equal(res["fp8+bf16"][0], res["fp8"][0]) and not torch.equal(res["fp8"][0], res["bf16"][0])
+    assert torch.equal(res["fp8+bf16"][1], res["bf16"][1]) and not torch.equal(res["fp8"][1], res["bf16"][1])

@@ -210,11 +210,15 @@ def set_gemm_mode(mode):
     """Select the GEMM arithmetic; returns the previous name.
     "f32" exact-fp32 MFMA | "bf16x6" | "bf16x3" | "bf16": arithmetic of every vb_linear_* launch (C side);
     "fp8": FORWARD linears whose shape allows it run on quantised e4m3 operands (vb_linear_fwd_fp8, host-side weight
-    cache in ops.py); everything else - backward GEMMs, ineligible shapes - stays exact fp32."""
+    cache in ops.py); everything else - backward GEMMs, ineligible shapes - stays exact fp32;
+    "fp8+bf16": fp8 forward as above, every other GEMM (backward, ineligible shapes) in the bf16 mode."""
     prev_fp8 = _FP8["on"]
-    _FP8["on"] = mode == "fp8"
-    prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode == "fp8" else mode])
-    return "fp8" if prev_fp8 else {v: k for k, v in GEMM_MODES.items()}[prev]
+    _FP8["on"] = mode in ("fp8", "fp8+bf16")
+    prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode == "fp8" else "bf16" if mode == "fp8+bf16" else mode])
+    prev_name = {v: k for k, v in GEMM_MODES.items()}[prev]
+    if prev_fp8:
+        return "fp8+bf16" if prev_name == "bf16" else "fp8"
+    return prev_name
 
 
 def fp8_enabled():
