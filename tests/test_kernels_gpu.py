@@ -102,12 +102,13 @@ def test_linear_activation_derivative_and_multiplier_epilogues(ops, gemm_tile, c
     _close(dx, (dy.double() @ w.double()) * m.double(), 3e-5, 3e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(424, 1002, 256), (1628, 3054, 768)])
+@pytest.mark.parametrize("M,N,K", [(424, 1002, 256), (1628, 3054, 768), (300, 8190, 256), (1628, 30522, 768)])
 def test_linear_padded_logits_path_ragged_contraction(ops, M, N, K):
     """The MLM-decoder shape class: out-features N with N % 4 == 2 (30522), a row count that is no multiple of 16. The
     logits live in a buffer whose row stride is rounded up to 4 floats (pad_cols); the backward GEMMs read the strided
     gradient in place and split their contraction into an aligned bulk (second-generation kernel) + a <= 15-element
-    tail launch."""
+    tail launch. With >= 4096 out-features and a small dX (the last two cases, incl. the real decoder shape) the dgrad
+    bulk is additionally cut along K into atomically combined splits."""
     x, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3)
     y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [b.cuda()], pad_cols=True)
     assert y.shape == (M, N) and y.stride() == ((N + 3) // 4 * 4, 1)

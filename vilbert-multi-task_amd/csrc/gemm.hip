@@ -340,7 +340,8 @@ bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
     const int e = p.epi;
     const bool epi_ok = e == EPI_STORE || (FWD && (e == EPI_GELU || e == EPI_DGELU || e == EPI_RES_DROP)) ||
                         ((FWD || DGRAD) && e == EPI_RES) || (DGRAD && (e == EPI_MUL || e == EPI_ACCUM)) ||
-                        (!A_KC && (e == EPI_ATOMIC || e == EPI_ACCUM || splits != 1));
+                        (!A_KC && (e == EPI_ATOMIC || e == EPI_ACCUM || splits != 1)) ||
+                        (DGRAD && splits < 0 && e == EPI_ACCUM);   // split-K dgrad of a small output (vb_linear_bwd_input)
     if (!epi_ok) return false;
     const bool multi_seg = p.C[1] != nullptr;
     // plans are cached per problem shape (a training step launches the same ~30 shapes thousands of times)
@@ -552,18 +553,34 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
         // A contraction length that is not a multiple of 16 (the MLM decoder: 30522 out-features) would send the whole
         // GEMM to the round-1 kernel with scalar loads: run the aligned bulk on the second-generation kernel and
         // add the <= 15 leftover k with a second, tiny launch.
+        // A small output with a long contraction (the MLM decoder: dX [1628 x 768] over 30522 out-features = 136 tiles
+        // for 256 CUs, 66 TF) is cut along K as the wgrad launches are: the planner picks the split count and the splits
+        // add into dX with atomics (dX is zero-filled first unless it already holds a contribution).
+        const bool split_k = p.mul == nullptr && p.R == nullptr && (long)p.M * p.N <= 2048L * 1024 && p.K >= 4096 &&
+                             (p.epi == EPI_STORE || p.epi == EPI_ACCUM) && gemm_mode() == 0;
+        auto launch_main = [&](GemmP q, bool vq) -> int {
+            if (!split_k) return launch_gemm<true, false>(st, q, vq, 1);
+            if (q.epi == EPI_STORE) {
+                const hipError_t e =
+                    hipMemset2DAsync(q.C[0], q.ldc * sizeof(float), 0, (size_t)q.N * sizeof(float), q.M, st);
+                if (e != hipSuccess) return (int)e;
+            }
+            q.epi = EPI_ACCUM;
+            q.accumulate = 1;
+            return launch_gemm<true, false>(st, q, vq, -1);
+        };
         const int k_main = p.K / V2_BK * V2_BK;
         if (fused && a->nseg == 1 && k_main >= 256 && k_main != p.K && p.R == nullptr && p.mul == nullptr &&
             a->K % 4 == 0 && a->ldy % 4 == 0 && a->ldw % 4 == 0 && vb_aligned16(p.A) && vb_aligned16(p.B[0])) {
             GemmP m = p, t = p;
             m.K = k_main; m.bseg = k_main; m.ktiles_per_split = k_main / BK;
-            if (int e = launch_gemm<true, false>(st, m, true, 1)) return e;
+            if (int e = launch_main(m, true)) return e;
             t.K = p.K - k_main; t.bseg = t.K; t.A = p.A + k_main; t.B[0] = p.B[0] + (long)k_main * p.ldb;
             t.accumulate = 1; t.epi = EPI_ACCUM; t.ktiles_per_split = 1;
             if (int e = launch_gemm<true, false>(st, t, false, 1)) return e;
             continue;
         }
-        if (int e = launch_gemm<true, false>(st, p, vec, 1)) return e;
+        if (int e = launch_main(p, vec)) return e;
     }
     return 0;
 }

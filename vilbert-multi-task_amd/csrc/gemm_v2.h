@@ -437,7 +437,7 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
     }
     const int row0 = m0 + wm * 16 * TM + l15, col0 = n0 + wn * 16 * TN + 4 * g;
     // only the epilogues a layout can be launched with are instantiated: forward (NT) = store / gelu / residual /
-    // dropout; dgrad (NN) = store / residual / accumulate / multiply; wgrad (TN) = store / accumulate / atomic
+    // dropout; dgrad (NN) = store / residual / accumulate / multiply / atomic (split-K of a small output); wgrad (TN) = store / accumulate / atomic
     constexpr bool FWD = A_KC && B_KC, DGRAD = A_KC && !B_KC;
     if (FWD && p.epi == EPI_GELU) epilogue_v2<EPI_GELU, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
     else if (FWD && p.epi == EPI_DGELU) epilogue_v2<EPI_DGELU, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
@@ -445,6 +445,7 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
     else if ((FWD || DGRAD) && p.epi == EPI_RES) epilogue_v2<EPI_RES, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
     else if (DGRAD && p.epi == EPI_MUL) epilogue_v2<EPI_MUL, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
     else if (DGRAD && p.epi == EPI_ACCUM) epilogue_v2<EPI_ACCUM, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
+    else if (DGRAD && p.epi == EPI_ATOMIC) epilogue_v2<EPI_ATOMIC, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
     else epilogue_v2<EPI_STORE, TM, TN, FWD>(p, cbase, acc, row0, col0, lead, full);
 }
 
