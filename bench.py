@@ -25,11 +25,9 @@ for p in (os.path.join(ROOT, "vilbert-multi-task_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# data-parallel runs: the streams of the two-stream encoder + RCCL's own streams must not share hardware queues (see
-# vilbert/distributed.py); read by the HIP runtime at its first call, so it has to be in the environment before torch
-# touches the device. Single-GPU runs keep the default (a graph-replayed step is slower with 8 queues).
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-ddp" in sys.argv:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the step keeps up to four HIP streams busy (+ RCCL's): they must not share hardware queues (see vilbert/__init__.py);
+# read by the HIP runtime at its first call, so it has to be in the environment before torch touches the device
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -155,3 +155,37 @@ def test_ddp_world_size_one_with_two_streams_matches_unwrapped(no_dropout):
     finally:
         V.set_two_streams(prev)
         dist.destroy_process_group()
+
+
+def test_weight_gradient_side_streams_give_the_same_gradients(no_dropout):
+    """wgrad GEMMs on side streams of the text / image backward streams (autograd_ops._wgrad) vs everything in order:
+    same gradients over three passes (tied decoder / word-embedding slice: second writer joins the side streams),
+    same optimizer trajectory."""
+    import vilbert.vilbert as V
+    from vilbert import autograd_ops as A
+    from vilbert.optim import AdamW
+    cfg, sd, args = _setup()
+    prev2 = V.set_two_streams(True)
+    try:
+        def run(on):
+            prev = A.set_wgrad_stream(on)
+            try:
+                m = _model(cfg, sd)
+                opt = AdamW(m.parameters(), lr=1e-3)
+                out = []
+                for _ in range(3):
+                    opt.zero_grad()
+                    sum(l.sum() for l in m(*args)).backward()
+                    torch.cuda.synchronize()
+                    out.append(_grads(m))
+                    opt.step()
+                return out, {n: p.detach().clone() for n, p in m.named_parameters()}
+            finally:
+                A.set_wgrad_stream(prev)
+        (g_off, w_off), (g_on, w_on) = run(False), run(True)
+        assert A._WGRAD["streams"], "the side streams were never used"
+        for a, b in zip(g_off, g_on):
+            _assert_same(a, b, "wgrad streams on vs off", tol=1e-4)
+        _assert_same(w_off, w_on, "weights after 3 steps", tol=1e-4)
+    finally:
+        V.set_two_streams(prev2)

@@ -156,6 +156,36 @@ int main(int argc, char** argv) {
         err = do_check ? check(N, K, M, dy, 1, N, x, 1, K, dw, K, nullptr) : -1;
         printf("wgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
         tot_f += fl; tot_t += us;
+        if (getenv("LAB_STREAMS")) {
+            // backward-shaped concurrency experiment: 20 x (dgrad, wgrad) on ONE stream vs dgrad on stream 0 and the
+            // (off-critical-path) wgrad on stream 1 - does a second independent kernel fill the tails / prologues?
+            hipStream_t s0, s1;
+            CK(hipStreamCreate(&s0));
+            CK(hipStreamCreate(&s1));
+            wg.accumulate = 1;
+            for (int two = 0; two < 2; ++two) {
+                auto pair = [&] {
+                    if (vb_linear_bwd_input(s0, &g) || vb_linear_bwd_weight(two ? s1 : s0, &wg)) exit(1);
+                };
+                for (int i = 0; i < 3; ++i) pair();
+                CK(hipDeviceSynchronize());
+                hipEvent_t e0, e1, j;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&j));
+                CK(hipEventRecord(e0, s0));
+                CK(hipStreamWaitEvent(s1, e0, 0));
+                for (int i = 0; i < iters; ++i) pair();
+                CK(hipEventRecord(j, s1));
+                CK(hipStreamWaitEvent(s0, j, 0));
+                CK(hipEventRecord(e1, s0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  (dgrad + wgrad) x %d on %d stream(s): %9.1f us per pair  %6.1f TF\n", iters, two + 1,
+                       ms * 1e3 / iters, 2 * fl / (ms * 1e3 / iters) / 1e6);
+            }
+            CK(hipStreamDestroy(s0));
+            CK(hipStreamDestroy(s1));
+        }
         for (float* p : {x, w, b, y, dy, dx, dw, db}) CK(hipFree(p));
     }
     printf("aggregate: %.1f TF\n", tot_f / tot_t / 1e6);

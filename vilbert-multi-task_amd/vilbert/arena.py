@@ -102,6 +102,8 @@ class GradArena(object):
     def _end_pass(self):
         self._pass_id = None
         self._written.clear()
+        for hook in END_PASS_HOOKS:      # e.g. join the weight-gradient side streams (autograd_ops.py)
+            hook()
         for l in self._listeners:
             l.arena_backward_done()
 
@@ -139,6 +141,11 @@ class GradArena(object):
         """A fresh tensor object over the slice (autograd steals it: use_count 1, no copy)."""
         o, p = self.offsets[index], self.params[index]
         return self.flat[o:o + p.numel()].view(p.shape)
+
+
+# callables run at the end of every backward pass that wrote into an arena (engine callback, on the thread and stream that
+# called backward), before the arena's listeners
+END_PASS_HOOKS = []
 
 
 def claim(param):

@@ -23,18 +23,9 @@ Design for MI355X (8 GPUs, 7 xGMI links per GPU, 288 GB HBM each):
     for multi-task training) when the used set changes from step to step.
 Works with any ``torch.distributed`` backend (``nccl`` = RCCL on ROCm; ``gloo`` for the CPU tests).
 """
-import os
-
-# The two-stream encoder (text || image HIP streams) needs its streams on DIFFERENT hardware queues. HIP maps streams
-# round-robin onto GPU_MAX_HW_QUEUES (default 4) queues; once RCCL has created its own streams the side stream ends up
-# sharing a queue with the main stream and the overlap silently disappears (measured: DistributedDataParallel step
-# 117.0 ms with 4 queues, 111.5 ms with 8; plain step 110.5 ms). The variable is read when the HIP runtime initialises,
-# i.e. at the first device call - the training scripts import this module (as apex.parallel) at their top, in time.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-from torch import nn  # noqa: E402
+import torch
+import torch.distributed as dist
+from torch import nn
 
 from .arena import GradArena
 
@@ -140,6 +131,8 @@ class DistributedDataParallel(nn.Module):
 
     def _launch(self, b):
         """Start the in-place all-reduce of the bucket's arena range."""
+        from . import autograd_ops as _A
+        _A.join_wgrad_streams()      # weight gradients are written on side streams of the backward streams
         if b.streams:
             cur = torch.cuda.current_stream()
             for handle, st in b.streams.items():
