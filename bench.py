@@ -459,10 +459,12 @@ def main():
     # Roofline of the dominant kernel (the fp32-MFMA GEMM family, ~99 % of the FLOPs): every
     # vb_linear_fwd launch of extra profiled steps is bracketed with HIP events on the launch stream.
     prof_steps = 1 if args.mode == "train" else 2
-    # The profiled step runs on ONE stream: with the text / image streams overlapped an event pair would
-    # time a GEMM that shares the chip with the other stream's kernels, not the kernel itself.
+    # The profiled step runs on ONE stream: with the text / image streams (and the weight-gradient side streams)
+    # overlapped an event pair would time a GEMM that shares the chip with other streams' kernels, not the kernel itself.
+    from vilbert import autograd_ops as _ao
     from vilbert import vilbert as _vb
     two = _vb.set_two_streams(False)
+    ws_prev = _ao.set_wgrad_stream(False)
     pstep = step
     if args.graph and args.mode == "train":
         pstep = train_workload(B)[0]      # per-launch events need eager launches (same model, same optimizer)
@@ -474,6 +476,7 @@ def main():
     torch.cuda.synchronize()
     gemm_ms, gemm_flops, gemm_launches = ops.profile_linear(False)
     _vb.set_two_streams(two)
+    _ao.set_wgrad_stream(ws_prev)
     if args.gemm_breakdown and rank == 0:
         for tag, n, ms, tf in ops.profile_breakdown():
             print("gemm %-6s M=%6d N=%6d K=%6d nseg=%d  x%3d  %8.3f ms  %6.1f TF" % (tag + (n, ms, tf)), file=sys.stderr)
