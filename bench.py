@@ -334,9 +334,9 @@ def main():
         # same step replayed as ONE HIP graph
         e64, _, _ = train_workload(64)
         n64 = max(6, args.steps)
-        e_dt = timed(e64, 2, n64)
+        e_dt = timed(e64, 5, n64)
         g64, _, _ = train_workload(64, graph=True)
-        g_dt = timed(g64, 2, n64)
+        g_dt = timed(g64, 5, n64)
         for gs in train_state.pop("graphs", []):
             gs.check()
             gs.close()
