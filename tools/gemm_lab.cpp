@@ -156,6 +156,38 @@ int main(int argc, char** argv) {
         err = do_check ? check(N, K, M, dy, 1, N, x, 1, K, dw, K, nullptr) : -1;
         printf("wgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
         tot_f += fl; tot_t += us;
+        if (getenv("LAB_SPLIT")) {
+            // forward as ONE launch over M rows vs TWO launches over M / 2 rows each on two streams (micro-batch halves)
+            hipStream_t s0, s1;
+            CK(hipStreamCreate(&s0));
+            CK(hipStreamCreate(&s1));
+            vb_linear_args h0 = a, h1 = a;
+            h0.M = M / 2; h1.M = M - M / 2;
+            h1.A = x + (long)(M / 2) * K; h1.C = y + (long)(M / 2) * N;
+            for (int two = 0; two < 2; ++two) {
+                auto run = [&] {
+                    if (!two) { if (vb_linear_fwd(s0, &a)) exit(1); }
+                    else if (vb_linear_fwd(s0, &h0) || vb_linear_fwd(s1, &h1)) exit(1);
+                };
+                for (int i = 0; i < 3; ++i) run();
+                CK(hipDeviceSynchronize());
+                hipEvent_t e0, e1, j;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&j));
+                CK(hipEventRecord(e0, s0));
+                CK(hipStreamWaitEvent(s1, e0, 0));
+                for (int i = 0; i < iters; ++i) run();
+                CK(hipEventRecord(j, s1));
+                CK(hipStreamWaitEvent(s0, j, 0));
+                CK(hipEventRecord(e1, s0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  fwd x %d as %s: %9.1f us  %6.1f TF\n", iters, two ? "two half-batches on two streams" : "one launch",
+                       ms * 1e3 / iters, fl / (ms * 1e3 / iters) / 1e6);
+            }
+            CK(hipStreamDestroy(s0));
+            CK(hipStreamDestroy(s1));
+        }
         if (getenv("LAB_STREAMS")) {
             // backward-shaped concurrency experiment: 20 x (dgrad, wgrad) on ONE stream vs dgrad on stream 0 and the
             // (off-critical-path) wgrad on stream 1 - does a second independent kernel fill the tails / prologues?
