@@ -56,13 +56,16 @@ def _wgrad_stream(cur):
 
 
 def join_wgrad_streams(into=None, clear=False):
-    """Make `into` (default: the current stream) wait for every weight-gradient side stream with work in flight."""
+    """Make `into` (default: the current stream) wait for every weight-gradient side stream of ITS device with work in
+    flight (the bookkeeping is per device: backward threads of different devices never touch each other's entry)."""
     if _WGRAD["used"]:
         cur = into if into is not None else torch.cuda.current_stream()
-        for st in _WGRAD["used"].values():
-            cur.wait_stream(st)
-        if clear:
-            _WGRAD["used"].clear()
+        mine = _WGRAD["used"].get(cur.device.index)
+        if mine:
+            for st in list(mine.values()):
+                cur.wait_stream(st)
+            if clear:
+                mine.clear()
 
 
 _arena.END_PASS_HOOKS.append(lambda: join_wgrad_streams(clear=True))
@@ -115,7 +118,7 @@ def _wgrad(dy, x, weights, biases_present, need_w, need_b):
             dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
         dy.record_stream(ws)
         x.record_stream(ws)
-        _WGRAD["used"][ws.cuda_stream] = ws
+        _WGRAD["used"].setdefault(cur.device.index, {})[ws.cuda_stream] = ws
     else:
         dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
     return ([cw.out(s, dws[s]) if need_w[s] else None for s in range(nseg)],
