@@ -74,11 +74,11 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(long rows, int K, const
 // LDS per stage and operand: [128 rows][128 bytes]; the eight 16-byte chunks of a row are XOR-swizzled with
 // (row >> 1) & 7, so that the 16 lanes of a ds_read_b128 group (16 consecutive rows, same logical chunk) cover all
 // 64 banks once, and the 8 lanes of a ds_write_b128 group (one row, 8 chunks) a contiguous 128 bytes.
-// Staging global -> registers -> LDS, prefetch distance one K tile, one barrier per K tile (= 8 MFMAs of 64 cycles
-// per wave).
+// Staging global -> registers -> LDS through THREE register sets (tiles kt + 1 .. kt + 3 in flight while tile kt is
+// multiplied), one barrier per K tile (= 8 MFMAs of 64 cycles per wave). The epilogue issues all of its global reads
+// (row / column scales, bias, residual) before the first dependent use.
 // ---------------------------------------------------------------------------------------------------------------
-// abl (tools/fp8_lab.py, VB_FP8_ABL): 1 = no global stores / residual reads in the epilogue, 2 = one K tile only,
-// 3 = no epilogue arithmetic beyond the scale (plain store)
+// abl (tools/fp8_lab.py, VB_FP8_ABL): 1 = no global stores / residual reads in the epilogue, 2 = one K tile only
 struct Fp8X {
     const unsigned char* A; long lda;   // [M][K] bytes
     const unsigned char* B; long ldb;   // [N][K] bytes
