@@ -126,3 +126,20 @@ def test_gemm_kernels_keep_their_register_budget(native):
                 budget = 128 if small else 168
                 assert int(vgprs) <= budget, "%s uses %s VGPRs (budget %d)" % (fn, vgprs, budget)
     assert seen > 20
+
+
+def test_gemm_mode_names_round_trip_without_a_gpu(native):
+    """Mode selection is host state (C side: arithmetic of vb_linear_*; Python side: the fp8 forward switch)."""
+    first = native.set_gemm_mode("f32")
+    try:
+        for mode in ("bf16x6", "bf16x3", "bf16", "fp8", "fp8+bf16", "f32"):
+            native.set_gemm_mode(mode)
+            assert native.fp8_enabled() == mode.startswith("fp8")
+            assert native.set_gemm_mode(mode) == mode
+        with pytest.raises(KeyError):
+            native.set_gemm_mode("fp4")
+    finally:
+        native.set_gemm_mode(first)
+    e0 = native.WEIGHTS_EPOCH[0]
+    native.weights_changed()
+    assert native.WEIGHTS_EPOCH[0] == e0 + 1

@@ -212,6 +212,8 @@ def set_gemm_mode(mode):
     "fp8": FORWARD linears whose shape allows it run on quantised e4m3 operands (vb_linear_fwd_fp8, host-side weight
     cache in ops.py); everything else - backward GEMMs, ineligible shapes - stays exact fp32;
     "fp8+bf16": fp8 forward as above, every other GEMM (backward, ineligible shapes) in the bf16 mode."""
+    if mode not in GEMM_MODES and mode not in ("fp8", "fp8+bf16"):
+        raise KeyError("unknown GEMM mode %r (f32 | bf16x6 | bf16x3 | bf16 | fp8 | fp8+bf16)" % (mode,))
     prev_fp8 = _FP8["on"]
     _FP8["on"] = mode in ("fp8", "fp8+bf16")
     prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode == "fp8" else "bf16" if mode == "fp8+bf16" else mode])
