@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 9
+#define VB_ABI_VERSION 10
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -77,6 +77,14 @@ int vb_bump_counter(void* stream, uint64_t* device_counter);   /* *device_counte
  * {434, 433, 324, 323} = force that mixed-height pair, -1 = round-1 kernel only.
  * Returns the previous code; an unknown value only queries. Environment: VB_GEMM_TILE=<code>, VB_GEMM_V2=0. */
 int vb_set_gemm_tile(int code);
+
+/* Persistent one-block-per-CU fp32 GEMM (round 3; forward and dgrad layouts of vb_linear_fwd / vb_linear_bwd_input,
+ * replaces the same nn.Linear call sites - vilbert.py:425-427,471,501,514): 12 MFMA waves + 1 LDS-DMA loader wave per
+ * compute unit, 288 x 96 / 288 x 128 output tiles, the K tiles of all output tiles of a block streamed through a 4-stage
+ * LDS ring. mode: 0 = never, 1 = wherever its tiles fill whole rounds of the 256 compute units (default:
+ * >= 90 % of the launched tile slots useful, e.g. M = 9216 or 18432 rows), 2 = every eligible launch. Returns the previous mode; an unknown value only
+ * queries. Environment: VB_GEMM_V4=<mode>. */
+int vb_set_gemm_v4(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * vb_linear_fwd:  C[M, nseg*seg_n] = act( A[M,K] . W^T + bias ) (+ residual)

@@ -1,0 +1,120 @@
+"""Persistent one-block-per-CU GEMM kernel (csrc/gemm_v4.h: 12 MFMA waves + 1 LDS-DMA loader wave, 288 x 96 / 288 x 128
+tiles, K tiles of all output tiles of a block streamed through one LDS ring) against fp64, forced onto EVERY eligible
+launch (mode 2) so that the cases the planner would not pick are covered too: ragged last row tile, fewer tiles than
+compute units, several rounds of tiles per block (loader running across output-tile boundaries, the extra boundary
+barrier), stacked weight segments (forward: along N, dgrad: along K), both tile widths, every fused epilogue of the
+forward and dgrad layouts, the shortest legal contraction (two K steps), and bit-equality of repeated launches."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vilbert import ops as _ops
+    return _ops
+
+
+@pytest.fixture
+def v4():
+    from vilbert import _native
+    prev = _native.set_gemm_v4(2)
+    yield _native
+    _native.set_gemm_v4(prev)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def _gelu64(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _close(got, want64, rtol=3e-5, atol=3e-5):
+    got = got.detach().cpu().double()
+    err = (got - want64).abs()
+    assert got.shape == want64.shape and torch.isfinite(got).all()
+    assert (err <= atol + rtol * want64.abs()).all(), "max err %.3e (max |ref| %.3e)" % (err.max().item(), want64.abs().max().item())
+
+
+# (M, N per segment, K, nseg): one tile; ragged M (rows past the matrix are computed, never stored); 5 x 8 = 40 tiles
+# < 256 blocks; 3 segments x 96 (tile width 96 only); 1024-wide (128 only); two K steps; > 256 tiles (two rounds, the
+# second one partial: blocks with and without a second tile); three full rounds
+SHAPES = [(288, 96, 64, 1), (300, 384, 96, 1), (1440, 768, 160, 1), (576, 96, 128, 3), (900, 1024, 64, 1),
+          (288, 128, 32, 1), (288 * 9 + 17, 96 * 30, 64, 1), (288 * 32, 768, 64, 3)]
+
+
+@pytest.mark.parametrize("M,N,K,nseg", SHAPES)
+def test_forward_and_dgrad_match_fp64(ops, v4, M, N, K, nseg):
+    x = _rand(M, K, seed=1)
+    ws = [_rand(N, K, seed=10 + i, scale=0.1) for i in range(nseg)]
+    bs = [_rand(N, seed=20 + i) for i in range(nseg)]
+    dy = _rand(M, nseg * N, seed=3)
+    xd, wd = x.cuda(), [w.cuda() for w in ws]
+    y, _ = ops.linear_fwd(xd, wd, [b.cuda() for b in bs])
+    _close(y, torch.cat([x.double() @ w.double().t() + b.double() for w, b in zip(ws, bs)], 1))
+    dx = ops.linear_bwd_input(dy.cuda(), wd, K)
+    _close(dx, dy.double() @ torch.cat(ws, 0).double(), 3e-5, 3e-5 * max(1.0, N * nseg / 256))
+    # the planner's own choice (mode 1) and the 4-wave kernels (mode 0) give the same numbers up to summation order
+    for mode in (1, 0):
+        v4.set_gemm_v4(mode)
+        y2, _ = ops.linear_fwd(xd, wd, [b.cuda() for b in bs])
+        assert (y2 - y).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    v4.set_gemm_v4(2)
+
+
+def test_repeated_launches_are_bit_identical(ops, v4):
+    x, w = _rand(288 * 3, 256, seed=5).cuda(), _rand(96 * 4, 256, seed=6, scale=0.1).cuda()
+    a, _ = ops.linear_fwd(x, [w], [None])
+    for _ in range(3):
+        b, _ = ops.linear_fwd(x, [w], [None])
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K", [(288 * 2, 96 * 4, 64), (320, 256, 96)])
+def test_fused_epilogues(ops, v4, M, N, K):
+    """gelu, gelu + stored derivative, residual, dropout + residual (mask = the vb_dropout function of seed and
+    element index), dgrad with the multiplier / residual-gradient epilogues."""
+    x, w, b = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1), _rand(N, seed=9)
+    r = _rand(M, N, seed=10)
+    xd, wd, bd = x.cuda(), [w.cuda()], [b.cuda()]
+    pre = x.double() @ w.double().t() + b.double()
+    y, _ = ops.linear_fwd(xd, wd, bd, act="gelu")
+    _close(y, _gelu64(pre))
+    y, d = ops.linear_fwd(xd, wd, bd, act="gelu", want_act_grad=True)
+    p2 = pre.clone().requires_grad_(True)
+    _gelu64(p2).sum().backward()
+    _close(y, _gelu64(pre))
+    _close(d, p2.grad)
+    y, _ = ops.linear_fwd(xd, wd, bd, residual=r.cuda())
+    _close(y, pre + r.double())
+    # dropout before the residual: compare with the stand-alone dropout kernel applied to the plain product
+    plain, _ = ops.linear_fwd(xd, wd, bd)
+    y, _ = ops.linear_fwd(xd, wd, bd, residual=r.cuda(), drop_p=0.25, seed=1234)
+    want = ops.dropout(plain, 0.25, 1234) + r.cuda()
+    assert (y - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    kept = (y - r.cuda()).abs() > 0
+    assert 0.6 < kept.float().mean().item() < 0.9
+    dy, m = _rand(M, N, seed=11), _rand(M, K, seed=12)
+    dx = ops.linear_bwd_input(dy.cuda(), wd, K, mul=m.cuda())
+    _close(dx, (dy.double() @ w.double()) * m.double())
+    dx = ops.linear_bwd_input(dy.cuda(), wd, K, residual=m.cuda())
+    _close(dx, dy.double() @ w.double() + m.double())
+
+
+def test_planner_picks_the_persistent_kernel_only_where_it_fills_the_chip(ops):
+    """Mode 1 (default): same results whichever kernel runs; this test pins that the default mode is 1 and that the
+    text-stream shape of the batch-256 step (9216 rows) goes through it without error, next to a shape that stays on
+    the 4-wave kernels (batch-64 rows)."""
+    from vilbert import _native
+    assert _native.set_gemm_v4(1) == 1
+    for M in (9216, 2304):
+        x, w = _rand(M, 768, seed=1), _rand(768, 768, seed=2, scale=0.05)
+        y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [None])
+        rows = torch.arange(0, M, 97)
+        _close(y[rows], x[rows].double() @ w.double().t())

@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <map>
 #include <vector>
 
 #include "../include/vilbert_hip.h"
@@ -91,30 +93,152 @@ static double check(int M, int N, int K, const float* A, long a_rs, long a_cs, c
 }
 
 extern "C" void vblab_gemm_cycles(unsigned long long* dev_buf);
-static unsigned long long* g_cyc = nullptr;
-// cycles per K step of one block (block 128) in the last launch, and the implied shader clock given the wall time
-static void report_cycles(double us) {
-    unsigned long long h[2];
-    CK(hipMemcpy(h, g_cyc, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[1] > 0) printf("        block 128: %llu cycles / %llu K steps = %.0f cycles per step; loop span %.1f%% of the launch at 2.4 GHz\n",
-                         h[0], h[1], (double)h[0] / h[1], 100.0 * h[0] / 2400.0 / us);
+// LAB_TIMELINE=1 (library built with LAB=1): one instrumented launch per shape / kind; every block records realtime
+// (100 MHz) stamps {start, after prologue, after K loop, after epilogue} + shader cycles; summary per launch.
+static const int TL_MAX_BLOCKS = 1 << 16;
+static unsigned long long* g_tl = nullptr;
+template <class F>
+static void timeline(const char* kind, F fn) {
+    if (!getenv("LAB_TIMELINE")) return;
+    if (!g_tl) CK(hipMalloc(&g_tl, (size_t)TL_MAX_BLOCKS * 64 + 256 * 128 + 3000 * 8));
+    for (int rep = 0; rep < 2; ++rep) {
+    CK(hipMemset(g_tl, 0, (size_t)TL_MAX_BLOCKS * 64 + 256 * 128 + 3000 * 8));
+    fn(); fn();
+    CK(hipDeviceSynchronize());
+    vblab_gemm_cycles(g_tl);
+    fn();
+    CK(hipDeviceSynchronize());
+    vblab_gemm_cycles(nullptr);
+    std::vector<unsigned long long> h((size_t)TL_MAX_BLOCKS * 8);
+    CK(hipMemcpy(h.data(), g_tl, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> st, pro, loop, epi, en, clk;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    int per_xcd[8] = {0};
+    for (int b = 0; b < TL_MAX_BLOCKS; ++b) {
+        const unsigned long long* r = &h[(size_t)b * 8];
+        if (r[0] == 0 || r[3] == 0) continue;
+        if (r[0] < t0) t0 = r[0];
+        if (r[3] > t1) t1 = r[3];
+    }
+    for (int b = 0; b < TL_MAX_BLOCKS; ++b) {
+        const unsigned long long* r = &h[(size_t)b * 8];
+        if (r[0] == 0 || r[3] == 0) continue;
+        st.push_back((r[0] - t0) * 0.01); pro.push_back((r[1] - r[0]) * 0.01); loop.push_back((r[2] - r[1]) * 0.01);
+        epi.push_back((r[3] - r[2]) * 0.01); en.push_back((r[3] - t0) * 0.01);
+        if (r[3] > r[0]) clk.push_back((double)(r[5] - r[4]) / ((r[3] - r[0]) * 10.0));
+        per_xcd[(r[6] >> 32) & 7]++;
+    }
+    if (st.empty()) { printf("  timeline %s: no stamps (library not built with LAB=1?)\n", kind); return; }
+    auto stat = [](std::vector<double> v, const char* name) {
+        std::sort(v.begin(), v.end());
+        double s = 0; for (double x : v) s += x;
+        printf("    %-9s min %7.2f  p10 %7.2f  med %7.2f  p90 %7.2f  max %7.2f  mean %7.2f\n", name, v.front(), v[v.size() / 10],
+               v[v.size() / 2], v[v.size() * 9 / 10], v.back(), s / v.size());
+    };
+    printf("  timeline %s rep %d: %zu blocks, span %.2f us (first start -> last end), blocks per XCD %d %d %d %d %d %d %d %d\n", kind, rep, st.size(),
+           (t1 - t0) * 0.01, per_xcd[0], per_xcd[1], per_xcd[2], per_xcd[3], per_xcd[4], per_xcd[5], per_xcd[6], per_xcd[7]);
+    stat(st, "start us"); stat(pro, "prologue"); stat(loop, "K loop"); stat(epi, "epilogue"); stat(en, "end us"); stat(clk, "clk GHz");
+    {   // persistent kernel (gemm_v4.h): the loader waves' cycle split
+        std::vector<unsigned long long> ls(256 * 16);
+        CK(hipMemcpy(ls.data(), g_tl + (size_t)TL_MAX_BLOCKS * 8, ls.size() * 8, hipMemcpyDeviceToHost));
+        double a = 0, v = 0, bb = 0, n = 0, steps = 0;
+        for (int i = 0; i < 256; ++i) if (ls[16 * i + 3]) { a += ls[16 * i]; v += ls[16 * i + 1]; bb += ls[16 * i + 2]; steps += ls[16 * i + 3]; n++; }
+        {   // block 0, MFMA wave 0: per K step cycles and clock
+            std::vector<unsigned long long> sp(3000);
+            CK(hipMemcpy(sp.data(), g_tl + (size_t)TL_MAX_BLOCKS * 8 + 16 * 256, sp.size() * 8, hipMemcpyDeviceToHost));
+            int ns = 0;
+            while (ns < 1000 && sp[3 * ns + 1]) ++ns;
+            if (ns > 8) {
+                printf("    block 0 wave 0, %d steps: [step: cycles since previous barrier exit | cycles waiting at the barrier | clock GHz]\n     ", ns);
+                for (int i = 1; i < ns; ++i) {
+                    const double dt = (sp[3 * i + 2] - sp[3 * (i - 1) + 2]) * 10.0;   // ns
+                    if (i < 12 || i % 8 == 0 || i > ns - 6)
+                        printf(" [%d: %llu | %llu | %.2f]", i, sp[3 * i + 1] - sp[3 * (i - 1) + 1], sp[3 * i + 1] - sp[3 * i], dt > 0 ? (sp[3 * i + 1] - sp[3 * (i - 1) + 1]) / dt : 0.0);
+                }
+                printf("\n");
+            }
+        }
+        for (int blk : {0, 100}) {
+            if (!ls[16 * blk + 3]) continue;
+            printf("    block %d rounds (us since block start): ", blk);
+            for (int r = 0; r < 6 && ls[16 * blk + 4 + 2 * r]; ++r)
+                printf(" [K loop end %.2f, epilogue end %.2f]", (ls[16 * blk + 4 + 2 * r] - h[(size_t)blk * 8]) * 0.01, (ls[16 * blk + 5 + 2 * r] - h[(size_t)blk * 8]) * 0.01);
+            printf("\n");
+        }
+        if (n > 0) printf("    loader waves (%g): per K step %.0f cycles issuing, %.0f waiting for DMA, %.0f at the barrier (total %.0f)\n", n,
+                          a / steps, v / steps, bb / steps, (a + v + bb) / steps);
+    }
+    // per compute unit (key = XCC id, HW_ID bits [15:8] = se / sh / cu): blocks placed there, when its last block ended,
+    // and the K-loop time of its blocks summed (= how long the unit's matrix pipes had this launch's work queued)
+    struct Cu { int n = 0; double last = 0, first_end = 1e30, ksum = 0; };
+    std::map<unsigned, Cu> cus;
+    for (int b = 0; b < TL_MAX_BLOCKS; ++b) {
+        const unsigned long long* r = &h[(size_t)b * 8];
+        if (r[0] == 0 || r[3] == 0) continue;
+        Cu& c = cus[(unsigned)(((r[6] >> 32) & 7) << 8 | ((r[6] >> 8) & 0xff))];
+        c.n++;
+        c.last = std::max(c.last, (r[3] - t0) * 0.01);
+        c.first_end = std::min(c.first_end, (r[3] - t0) * 0.01);
+        c.ksum += (r[2] - r[1]) * 0.01;
+    }
+    std::map<int, int> hist;
+    std::vector<double> last, first;
+    for (auto& kv : cus) { hist[kv.second.n]++; last.push_back(kv.second.last); first.push_back(kv.second.first_end); }
+    printf("    %zu compute units; blocks per unit:", cus.size());
+    for (auto& kv : hist) printf("  %d x%d", kv.first, kv.second);
+    printf("\n");
+    stat(first, "CU 1st end"); stat(last, "CU last end");
+    for (auto& kv : hist) {
+        std::vector<double> v;
+        for (auto& c : cus) if (c.second.n == kv.first) v.push_back(c.second.last);
+        char nm[32]; snprintf(nm, sizeof nm, "last|n=%d", kv.first);
+        stat(v, nm);
+    }
+    }
+}
+
+extern "C" int vb_set_gemm_v4(int mode);
+// LAB_V4_AB=1: the 4-wave kernels (mode 0) against the persistent kernel forced (mode 2), alternating in one process
+template <class F>
+static void v4_ab(const char* kind, double fl, F fn) {
+    if (!getenv("LAB_V4_AB")) return;
+    double best[2] = {1e30, 1e30};
+    for (int rep = 0; rep < 3; ++rep)
+        for (int m = 0; m < 2; ++m) {
+            vb_set_gemm_v4(m ? 2 : 0);
+            best[m] = std::min(best[m], time_us(fn, 20));
+        }
+    vb_set_gemm_v4(1);
+    printf("  A/B %-5s 4-wave %8.1f us %6.1f TF | persistent %8.1f us %6.1f TF | %+5.1f %%\n", kind, best[0], fl / best[0] / 1e6, best[1],
+           fl / best[1] / 1e6, 100.0 * (best[0] / best[1] - 1.0));
 }
 
 struct Shape { int M, N, K, nseg; };
 
 int main(int argc, char** argv) {
-    const bool quick = argc > 1 && !strcmp(argv[1], "quick");
-    const bool do_check = !(argc > 1 && !strcmp(argv[1], "nocheck"));
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    bool quick = false, do_check = true;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "quick")) quick = true;
+        if (!strcmp(argv[i], "nocheck")) do_check = false;
+    }
     const int Mr = getenv("LAB_M") ? atoi(getenv("LAB_M")) : 9216;
     std::vector<Shape> shapes = {{Mr, 768, 768, 1}, {Mr, 768, 768, 3}, {Mr, 3072, 768, 1}, {Mr, 768, 3072, 1},
                                  {Mr, 1024, 1024, 1}, {Mr, 1024, 1024, 3}, {Mr, 1024, 768, 3}, {Mr, 1024, 2048, 1}};
+    if (getenv("LAB_LARGE")) shapes = {{Mr, 1024, 1024, 1}, {Mr, 1024, 1024, 3}, {Mr, 4096, 1024, 1}, {Mr, 1024, 4096, 1}};
     if (quick) shapes = {{Mr, 768, 768, 1}, {Mr, 3072, 768, 1}, {Mr, 1024, 1024, 3}};
     printf("VB_GEMM_V2=%s VB_GEMM_TILE=%s VB_GEMM_ABL=%s M=%d\n", getenv("VB_GEMM_V2") ? getenv("VB_GEMM_V2") : "-",
            getenv("VB_GEMM_TILE") ? getenv("VB_GEMM_TILE") : "-", getenv("VB_GEMM_ABL") ? getenv("VB_GEMM_ABL") : "-", Mr);
-    CK(hipMalloc(&g_cyc, 16));
-    CK(hipMemset(g_cyc, 0, 16));
-    if (getenv("LAB_CYCLES")) vblab_gemm_cycles(g_cyc);
     double tot_f = 0, tot_t = 0;
+    {   // clock warm-up: ~0.3 s of back-to-back GEMMs before anything is timed (the shader clock ramps over milliseconds)
+        const int M = 9216, N = 3072, K = 768;
+        float* x = dev_rand((long)M * K, 1, 1.0f); float* w = dev_rand((long)N * K, 2, 0.05f); float* y = dev_rand((long)M * N, 4, 0.0f);
+        vb_linear_args a; memset(&a, 0, sizeof(a));
+        a.M = M; a.K = K; a.nseg = 1; a.seg_n = N; a.A = x; a.lda = K; a.ldw = K; a.C = y; a.ldc = N; a.W[0] = w;
+        for (int i = 0; i < (getenv("LAB_WARM") ? atoi(getenv("LAB_WARM")) : 800); ++i) vb_linear_fwd(nullptr, &a);
+        CK(hipDeviceSynchronize());
+        for (float* p : {x, w, y}) CK(hipFree(p));
+    }
     for (const Shape& s : shapes) {
         const int M = s.M, n = s.N, K = s.K, nseg = s.nseg, N = n * nseg;
         float* x = dev_rand((long)M * K, 1, 1.0f);
@@ -135,7 +259,8 @@ int main(int argc, char** argv) {
         double us = time_us([&] { int e = vb_linear_fwd(nullptr, &a); if (e) { fprintf(stderr, "fwd err %d\n", e); exit(1); } }, iters);
         double err = do_check ? check(M, N, K, x, K, 1, w, K, 1, y, N, b) : -1;
         printf("fwd   M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
-        if (getenv("LAB_CYCLES")) report_cycles(us);
+        timeline("fwd", [&] { vb_linear_fwd(nullptr, &a); });
+        v4_ab("fwd", fl, [&] { vb_linear_fwd(nullptr, &a); });
         tot_f += fl; tot_t += us;
         // dgrad: dx[M,K] = dy[M,N] . W[N,K]
         vb_linear_bwd_input_args g;
@@ -145,7 +270,8 @@ int main(int argc, char** argv) {
         us = time_us([&] { int e = vb_linear_bwd_input(nullptr, &g); if (e) { fprintf(stderr, "dgrad err %d\n", e); exit(1); } }, iters);
         err = do_check ? check(M, K, N, dy, N, 1, w, 1, K, dx, K, nullptr) : -1;
         printf("dgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
-        if (getenv("LAB_CYCLES")) report_cycles(us);
+        timeline("dgrad", [&] { vb_linear_bwd_input(nullptr, &g); });
+        v4_ab("dgrad", fl, [&] { vb_linear_bwd_input(nullptr, &g); });
         tot_f += fl; tot_t += us;
         // wgrad: dw[N,K] = dy^T . x (+ bias gradient)
         vb_linear_bwd_weight_args wg;
@@ -155,6 +281,7 @@ int main(int argc, char** argv) {
         us = time_us([&] { int e = vb_linear_bwd_weight(nullptr, &wg); if (e) { fprintf(stderr, "wgrad err %d\n", e); exit(1); } }, iters);
         err = do_check ? check(N, K, M, dy, 1, N, x, 1, K, dw, K, nullptr) : -1;
         printf("wgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
+        timeline("wgrad", [&] { vb_linear_bwd_weight(nullptr, &wg); });
         tot_f += fl; tot_t += us;
         if (getenv("LAB_SPLIT")) {
             // forward as ONE launch over M rows vs TWO launches over M / 2 rows each on two streams (micro-batch halves)

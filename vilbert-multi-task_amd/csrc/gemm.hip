@@ -392,6 +392,46 @@ bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
     return ok;
 }
 
+// Persistent one-block-per-CU kernel (gemm_v4.h): -> tile width code (3 = 96, 4 = 128 columns) or 0 = not used. Called
+// after plan_v2 accepted the launch (alignment, epilogue). Mode (vb_set_gemm_v4 / VB_GEMM_V4): 0 = never, 1 = wherever
+// its tiles fill whole rounds of the 256 CUs (default), 2 = every eligible launch (tests, lab).
+// Measured in one process on the product library (tools/gemm_lab_prod LAB_V4_AB=1, profiles/r03_gemm_lab_v4_ab*.txt):
+// +2 ... +13 % on every forward / dgrad shape of the model at M = 9216 and 18432 (137-147 TF against 120-136 for the
+// 4-wave blocks on the same box), bert_large shapes included.
+int g_gemm_v4 = -1;
+
+int gemm_v4_mode() {
+    if (g_gemm_v4 < 0) {
+        const char* e = getenv("VB_GEMM_V4");
+        g_gemm_v4 = e != nullptr ? atoi(e) : 1;
+        if (g_gemm_v4 < 0 || g_gemm_v4 > 2) g_gemm_v4 = 1;
+    }
+    return g_gemm_v4;
+}
+
+int plan_v4(const GemmP& p, bool b_kc) {
+    const int mode = gemm_v4_mode();
+    if (mode == 0) return 0;
+    if (p.K % 32 != 0 || p.C[1] != nullptr || p.epi == EPI_ATOMIC || p.epi == EPI_GENERIC || p.epi == EPI_PRE_GELU) return 0;
+    static const int force_tn = [] { const char* e = getenv("VB_GEMM_V4_TN"); return e ? atoi(e) : 0; }();
+    const int rows = (p.M + 287) / 288;
+    double best = 0.0;
+    int best_tn = 0;
+    long best_tiles = 0;
+    for (int tn = 4; tn >= 3; --tn) {          // ties go to the wider tile (fewer operand bytes per flop)
+        if (p.N % (32 * tn) != 0 || (force_tn != 0 && force_tn != tn)) continue;
+        if (b_kc && p.B[1] != nullptr && p.bseg % (32 * tn) != 0) continue;   // a tile must not straddle two stacked weights
+        const long tiles = (long)rows * (p.N / (32 * tn));
+        // useful fraction of the launch: whole rounds of 256 blocks, the rows past M of the last row tile are wasted
+        const double eff = (double)tiles / (double)((tiles + 255) / 256 * 256) * ((double)p.M / (rows * 288.0));
+        if (eff > best + 1e-9) { best = eff; best_tn = tn; best_tiles = tiles; }
+    }
+    if (best_tn == 0) return 0;
+    if (mode == 2) return best_tn;
+    (void)best_tiles;
+    return best >= 0.90 ? best_tn : 0;
+}
+
 // splits: 1 = no split-K; < 0 = split-K launch (wgrad), choose the count; legacy_splits = count for the round-1 kernel
 template <bool A_KC, bool B_KC>
 int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits = 1, int vec_v2 = -1) {
@@ -405,6 +445,11 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     // vec_v2: 16-byte loads legal for the second-generation kernel (it tolerates a row-contiguous A whose row count is
     // not a multiple of 4 when the leading dimension leaves room for the last float4); default = same as `vec`
     if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec_v2 < 0 ? vec : vec_v2 != 0, splits, pl)) {
+        // persistent 288-row tiles (gemm_v4.h) where they fill the chip in whole rounds
+        if (A_KC && splits == 1) {
+            const int tn4 = plan_v4(p, B_KC);
+            if (tn4 != 0) return B_KC ? launch_gemm_v4_nt(st, p, tn4) : launch_gemm_v4_nn(st, p, tn4);
+        }
         p.tiles_n = pl.tiles_n;
         p.ktiles_per_split = pl.kt_per_split;
         p.n_big = pl.big_rows * pl.tiles_n;
@@ -468,6 +513,12 @@ extern "C" int vb_set_gemm_tile(int code) {
     if (code == -1 || code == 0 || code == 22 || code == 33 || code == 34 || code == 43 || code == 44 || code == 434 ||
         code == 433 || code == 324 || code == 323)
         g_gemm_tile = code;
+    return prev;
+}
+
+extern "C" int vb_set_gemm_v4(int mode) {
+    const int prev = gemm_v4_mode();
+    if (mode >= 0 && mode <= 2) g_gemm_v4 = mode;
     return prev;
 }
 

@@ -207,6 +207,9 @@ int launch_mul_inplace(hipStream_t st, long rows, int cols, float* c, long ldc, 
 int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits);
 int launch_gemm_v2_nn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits);
 int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits);
+// persistent one-block-per-CU kernels (gemm_v4.h): 288 x (32 tn) tiles, forward / dgrad layouts, no split-K
+int launch_gemm_v4_nt(hipStream_t st, const GemmP& p, int tn);
+int launch_gemm_v4_nn(hipStream_t st, const GemmP& p, int tn);
 
 // bf16-planes kernels (gemm_planes.hip, one object per plane count): launch for operand layouts (a_kc, b_kc)
 int launch_gemm_planes3(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);

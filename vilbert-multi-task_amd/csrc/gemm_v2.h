@@ -292,7 +292,12 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const unsigned long long t_start = p.dbg != nullptr ? __builtin_readcyclecounter() : 0ull;
+#ifdef VB_GEMM_LAB
+    // lab timeline (tools/gemm_lab LAB_TIMELINE=1): per block {realtime start, after prologue, after K loop, after
+    // epilogue (stores drained), shader cycles start, end, hardware id}; realtime = s_memrealtime, 100 MHz
+    unsigned long long* const tl = p.dbg != nullptr ? p.dbg + 8 * ((long)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+    if (tl != nullptr && tid == 0) { tl[0] = wall_clock64(); tl[4] = __builtin_readcyclecounter(); }
+#endif
     // ---- prologue: tiles 0, 1 into stages 0, 1; tiles 2 .. NSET + 1 in flight ----------------------------------
     load_tile(0);
     store_tile(smem, 0);
@@ -303,6 +308,9 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
     if (nk > 2) load_tile(0);
     if (NSET == 2 && nk > 3) load_tile(1);
     __syncthreads();
+#ifdef VB_GEMM_LAB
+    if (tl != nullptr && tid == 0) tl[1] = wall_clock64();
+#endif
 
     // fragment registers: first-half A tiles and all B tiles are double buffered (set = K step parity), the
     // second-half A tiles are read at the top of their own step
@@ -417,10 +425,24 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
         else tail_step(t + 2 < nk, t + 2 + NSET < nk, t + 1 < nk, std::integral_constant<int, 0>{});
     }
 
-    if (p.dbg != nullptr && blockIdx.x == 128 && blockIdx.y == 0 && tid == 0) {
-        p.dbg[0] = __builtin_readcyclecounter() - t_start;   // main-loop span of one block, shader cycles
-        p.dbg[1] = (unsigned long long)nk;
-    }
+#ifdef VB_GEMM_LAB
+    if (tl != nullptr && tid == 0) tl[2] = wall_clock64();
+    struct LabEnd {
+        unsigned long long* tl; int tid;
+        __device__ ~LabEnd() {
+            if (tl == nullptr) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) {
+                tl[3] = wall_clock64();
+                tl[5] = __builtin_readcyclecounter();
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                tl[6] = ((unsigned long long)xcc << 32) | hw;
+            }
+        }
+    } lab_end{tl, tid};
+#endif
     // ---- epilogue ----------------------------------------------------------------------------------------------
     const int cs = m0 / p.cseg;                 // C row segment of this tile (tiles never straddle segments)
     const int mloc = m0 - cs * p.cseg;

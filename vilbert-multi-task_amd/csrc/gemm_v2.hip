@@ -4,7 +4,7 @@
 //   -DVB_V2_LAYOUT=2  wgrad    (TN)  A row-contiguous, B row-contiguous
 // Each object instantiates the tile menu {64x64, 96x96, 96x128, 128x96, 128x128} (block tile = 32 TM x 32 TN) and the
 // mixed-height launches {128 | 96} x {128, 96}, {96 | 64} x {128, 96}.
-#include "gemm_v2.h"
+#include "gemm_v4.h"
 
 #ifndef VB_V2_LAYOUT
 #error "compile with -DVB_V2_LAYOUT=0|1|2"
@@ -36,10 +36,35 @@ __global__ __launch_bounds__(256, (V2Cfg<TM1, TN, A_KC, B_KC>::OCC)) void gemm_v
     }
 }
 
+#ifdef VB_GEMM_LAB
+// (laboratory only: measured slower - three 5-wave blocks do not co-reside on a CU - kept as the record of the experiment)
+// wave-specialised variant (gemm_v3.h): 4 MFMA waves + 1 LDS-DMA loader wave per block, same tile map
+template <int TM1, int TM2, int TN>
+__global__ __launch_bounds__(320, (V3Cfg<TM1, TN, A_KC, B_KC>::MIN_WAVES_PER_SIMD)) void gemm_v3_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (TM1 == TM2 || b < p.n_big) {
+        const int t = xcd_swizzle(b, TM1 == TM2 ? (int)gridDim.x : p.n_big);
+        gemm_tile_v3<TM1, TN, A_KC, B_KC>(p, smem, (t / p.tiles_n) * (32 * TM1), (t % p.tiles_n) * (32 * TN));
+    } else {
+        const int t = xcd_swizzle(b - p.n_big, (int)gridDim.x - p.n_big);
+        gemm_tile_v3<TM2, TN, A_KC, B_KC>(p, smem, p.m_split + (t / p.tiles_n) * (32 * TM2), (t % p.tiles_n) * (32 * TN));
+    }
+}
+
+#endif
+
 template <int TM1, int TM2, int TN>
 int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
     using Cfg = V2Cfg<TM1, TN, A_KC, B_KC>;   // TM1 >= TM2: the taller tile sets the LDS size and the register budget
     dim3 grid(tiles, splits), block(256);
+#ifdef VB_GEMM_LAB
+    if (p.flags & 2) {
+        hipLaunchKernelGGL((gemm_v3_kernel<TM1, TM2, TN>), grid, dim3(320), (V3Cfg<TM1, TN, A_KC, B_KC>::LDS_BYTES), st, p);
+        VB_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     // lab knob: extra dynamic LDS per block = fewer co-resident blocks per CU (occupancy experiments)
     static const int lds_pad = [] { const char* e = getenv("VB_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
     const int lds_bytes = Cfg::LDS_BYTES + lds_pad;
@@ -61,6 +86,29 @@ int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
     return 0;
 }
 
+#if VB_V2_LAYOUT != 2
+// persistent one-block-per-CU kernel (gemm_v4.h): 288 x 96 (TN = 3) / 288 x 128 (TN = 4) tiles
+template <int TN>
+__global__ __launch_bounds__(V4_THREADS, 4) void gemm_v4_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_block_v4<3, TN, B_KC>(p, smem);
+}
+
+template <int TN>
+int launch_v4(hipStream_t st, GemmP p) {
+    using Cfg = V4Cfg<3, TN, B_KC>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<TN>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    p.tiles_n = p.N / Cfg::BN;
+    p.n_big = ((p.M + Cfg::BM - 1) / Cfg::BM) * p.tiles_n;
+    const int grid = p.n_big < 256 ? p.n_big : 256;
+    hipLaunchKernelGGL((gemm_v4_kernel<TN>), dim3(grid), dim3(V4_THREADS), Cfg::LDS_BYTES, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+#endif
+
 int dispatch(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) {
     const int code = tm1 * 100 + tm2 * 10 + tn;
     switch (code) {
@@ -80,6 +128,11 @@ int dispatch(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles
 }  // namespace
 
 namespace vbgemm {
+#if VB_V2_LAYOUT == 0
+int launch_gemm_v4_nt(hipStream_t st, const GemmP& p, int tn) { return tn == 3 ? launch_v4<3>(st, p) : launch_v4<4>(st, p); }
+#elif VB_V2_LAYOUT == 1
+int launch_gemm_v4_nn(hipStream_t st, const GemmP& p, int tn) { return tn == 3 ? launch_v4<3>(st, p) : launch_v4<4>(st, p); }
+#endif
 #if VB_V2_LAYOUT == 0
 int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) { return dispatch(st, p, tm1, tm2, tn, tiles, splits); }
 #elif VB_V2_LAYOUT == 1

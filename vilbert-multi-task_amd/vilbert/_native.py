@@ -145,6 +145,7 @@ SIGNATURES = {
     "vb_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "vb_set_gemm_mode": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_gemm_tile": (ctypes.c_int, [ctypes.c_int]),
+    "vb_set_gemm_v4": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_seed_epoch": (ctypes.c_int, [_P]),
     "vb_bump_counter": (ctypes.c_int, [_P, _P]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
@@ -188,7 +189,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 9:
+        if handle.vb_abi_version() != 10:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") == "fp8":
@@ -200,6 +201,12 @@ def set_gemm_tile(code):
     """Tile selection of the fp32 GEMM: 0 = cost model, 22 | 33 | 34 | 43 | 44 = force a tile of the
     second-generation kernel, -1 = round-1 kernel only. Returns the previous code."""
     return lib().vb_set_gemm_tile(int(code))
+
+
+def set_gemm_v4(mode):
+    """Persistent one-block-per-CU GEMM kernel (csrc/gemm_v4.h): 0 = never, 1 = wherever its tiles fill whole
+    rounds of the 256 CUs (default), 2 = every eligible launch. Returns the previous mode."""
+    return lib().vb_set_gemm_v4(int(mode))
 
 
 GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}

@@ -18,17 +18,31 @@ Protocol used by autograd_ops.py (``claim`` / ``result``):
       mode "accum":  a later contribution of the same pass, or ``param.grad`` already IS the arena view (gradient
                      accumulation over micro-batches): the kernel adds into the view, the Function returns ``None``.
 If ``param.grad`` is some foreign tensor (a user assigned it), the parameter is left to plain autograd.
+
+Limits: a pass is keyed on autograd's graph-task id, so a NESTED backward (re-entrant checkpointing) inside a pass would
+re-begin it; the native autograd nodes never nest and the package does not checkpoint, so this is not supported.
 """
+import weakref
+
 import torch
 
-_BY_PTR = {}        # param.data_ptr() -> (arena, index)
+# param.data_ptr() -> (weak reference to the arena, index). Weak: an arena lives exactly as long as its owner (the
+# optimizer / data-parallel wrapper that built it) or a gradient view of it does; a long-lived process that builds many
+# models (test suites, bench legs, sweeps) must not keep every model-sized gradient buffer alive through this table.
+_BY_PTR = {}
 
 
 def lookup(param):
     e = _BY_PTR.get(param.data_ptr())
-    if e is None or e[0].params[e[1]].shape != param.shape:
+    if e is None:
         return None
-    return e
+    arena = e[0]()
+    if arena is None or arena.flat is None:
+        _BY_PTR.pop(param.data_ptr(), None)
+        return None
+    if arena.params[e[1]] is not param:
+        return None                  # the address was recycled by another tensor
+    return arena, e[1]
 
 
 class GradArena(object):
@@ -40,7 +54,7 @@ class GradArena(object):
         if dt != torch.float32:
             raise RuntimeError("GradArena holds fp32 gradients")
         self._cuda = dev.type == "cuda"     # (CPU tensors only in the gloo tests of the data-parallel wrapper)
-        self.params, self.offsets, seen, total = [], [], set(), 0
+        self.params, self.offsets, self.shapes, seen, total = [], [], [], set(), 0
         for p in params:
             if id(p) in seen:
                 continue
@@ -49,9 +63,10 @@ class GradArena(object):
                 raise RuntimeError("GradArena: all parameters must live on one device in fp32")
             self.params.append(p)
             self.offsets.append(total)
+            self.shapes.append(p.shape)
             total += (p.numel() + align_elems - 1) // align_elems * align_elems   # every slice stays 16-byte aligned
         self.flat = torch.zeros(total, device=dev, dtype=dt)
-        self.views = [self.flat[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+        self.views = [self.flat[o:o + sh.numel()].view(sh) for sh, o in zip(self.shapes, self.offsets)]
         self._written = set()          # indices claimed in the running backward pass
         self._pass_id = None           # autograd graph-task id of the running pass
         self._clean = True             # flat is all zeros
@@ -59,15 +74,17 @@ class GradArena(object):
         self._zero_event = None
         self._listeners = []           # objects with .arena_written(index) / .arena_backward_done()
         self._taken_over = 0
+        me = weakref.ref(self)
         for i, p in enumerate(self.params):
             old = _BY_PTR.get(p.data_ptr())
-            if old is not None and old[0] is not self:
+            old_arena = old[0]() if old is not None else None
+            if old_arena is not None and old_arena is not self and old_arena.flat is not None and old_arena.params[old[1]] is p:
                 # a newer arena (e.g. the data-parallel wrapper's bucket layout) takes the parameter over; an arena
                 # that lost all its parameters frees its buffer
-                old[0]._taken_over += 1
-                if old[0]._taken_over >= len(old[0].params):
-                    old[0].flat, old[0].views = None, []
-            _BY_PTR[p.data_ptr()] = (self, i)
+                old_arena._taken_over += 1
+                if old_arena._taken_over >= len(old_arena.params):
+                    old_arena.flat, old_arena.views = None, []
+            _BY_PTR[p.data_ptr()] = (me, i)
 
     # ------------------------------------------------------------------------------------------------------
     def add_listener(self, obj):
@@ -77,17 +94,51 @@ class GradArena(object):
         """Stop managing the parameters (their current .grad tensors stay valid views of the buffer)."""
         for p in self.params:
             e = _BY_PTR.get(p.data_ptr())
-            if e is not None and e[0] is self:
+            if e is not None and e[0]() in (self, None):
                 del _BY_PTR[p.data_ptr()]
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:      # interpreter shutdown
+            pass
 
     def owns(self, param, index):
         g = param.grad
         return g is not None and g.data_ptr() == self.views[index].data_ptr()
 
+    def enter_pass(self):
+        """Make sure the running backward pass has been begun (arena zero-filled unless accumulating). Called by claim()
+        and by anything that writes into the arena on its own during a backward pass - the data-parallel wrapper copies
+        the gradients of foreign (plain torch) autograd nodes into their slices and must not do so BEFORE the fill.
+        -> False outside a backward pass."""
+        task = torch._C._current_graph_task_id()
+        if task == -1:
+            return False
+        if self._pass_id != task:
+            self._pass_id = task
+            self._begin_pass()
+        return True
+
+    def wait_for_fill(self):
+        """Writers on another stream than the one that zero-filled the arena must wait for the fill."""
+        if self._cuda and self._zero_event is not None:
+            cur = torch.cuda.current_stream(self.flat.device)
+            if cur != self._zero_stream:
+                cur.wait_event(self._zero_event)
+
+    def note_foreign_write(self, index):
+        """The caller is about to write slice `index` itself during a backward pass (see enter_pass)."""
+        if self.enter_pass():
+            self.wait_for_fill()
+            self._written.add(index)
+
     def _begin_pass(self):
         """First claim of a backward pass: zero the arena unless gradients are being accumulated into it."""
         self._written.clear()
         accumulating = any(self.owns(p, i) for i, p in enumerate(self.params))
+        # an event of an earlier pass (possibly recorded inside a graph capture) must never order this pass
+        self._zero_event, self._zero_stream = None, None
         if not accumulating:
             if not self._clean:
                 self.flat.zero_()
@@ -113,17 +164,9 @@ class GradArena(object):
         if e is None or e[0] is not self:
             return None, None
         i = e[1]
-        task = torch._C._current_graph_task_id()
-        if task == -1:
+        if not self.enter_pass():
             return None, None                      # not inside a backward pass (manual call of a backward op)
-        if self._pass_id != task:
-            self._pass_id = task
-            self._begin_pass()
-        # writers on another stream than the one that zero-filled the arena must wait for the fill
-        if self._cuda and self._zero_event is not None:
-            cur = torch.cuda.current_stream(self.flat.device)
-            if cur != self._zero_stream:
-                cur.wait_event(self._zero_event)
+        self.wait_for_fill()
         if i in self._written:
             return self.views[i], "accum"
         g = param.grad
@@ -139,8 +182,8 @@ class GradArena(object):
 
     def alias(self, index):
         """A fresh tensor object over the slice (autograd steals it: use_count 1, no copy)."""
-        o, p = self.offsets[index], self.params[index]
-        return self.flat[o:o + p.numel()].view(p.shape)
+        o, sh = self.offsets[index], self.shapes[index]
+        return self.flat[o:o + sh.numel()].view(sh)
 
 
 # callables run at the end of every backward pass that wrote into an arena (engine callback, on the thread and stream that

@@ -112,7 +112,10 @@ class DistributedDataParallel(nn.Module):
         view = self.arena.views[i]
         g = param.grad
         if g is not None and g.data_ptr() != view.data_ptr():
-            # produced by a foreign autograd node: move it into the bucket (the native kernels write in place)
+            # produced by a foreign autograd node: move it into the bucket (the native kernels write in place).
+            # The arena's pass must have begun first: a foreign gradient can arrive before the first native claim()
+            # (a torch head on top of the native body), and the fill of that claim would otherwise wipe the copy.
+            self.arena.note_foreign_write(i)
             view.copy_(g)
         if b.launched:
             raise RuntimeError(
