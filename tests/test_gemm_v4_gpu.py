@@ -118,3 +118,36 @@ def test_planner_picks_the_persistent_kernel_only_where_it_fills_the_chip(ops):
         y, _ = ops.linear_fwd(x.cuda(), [w.cuda()], [None])
         rows = torch.arange(0, M, 97)
         _close(y[rows], x[rows].double() @ w.double().t())
+
+
+# (token rows = contraction, out-features per segment, in-features, segments): one tile with 1 / 2 splits; the three
+# stacked q | k | v weights (one dW tensor per segment, bias gradients fused); the text-stream shapes of the batch-256
+# step (W[768, 768]: 16 tiles x 16 splits = 256 units; W[3072, 768] / W[768, 3072]: 64 tiles x 4 splits); several
+# rounds of units per block (2 tiles x 8 col tiles x 18 splits = 288 units)
+WGRAD_SHAPES = [(256, 384, 96, 1), (512, 384, 192, 1), (1152, 384, 96, 3), (9216, 768, 768, 1), (9216, 3072, 768, 1),
+                (2304, 768, 3072, 1), (9216, 768, 768, 3), (4608, 768, 384, 1)]
+
+
+@pytest.mark.parametrize("M,N,K,nseg", WGRAD_SHAPES)
+def test_weight_gradient_matches_fp64(ops, v4, M, N, K, nseg):
+    x = _rand(M, K, seed=1)
+    dy = _rand(M, nseg * N, seed=3)
+    dws, dbs = ops.linear_bwd_weight(dy.cuda(), x.cuda(), nseg, N, [True] * nseg)
+    for s in range(nseg):
+        seg = dy[:, s * N:(s + 1) * N].double()
+        want = seg.t() @ x.double()
+        _close(dws[s], want, 3e-5, 3e-5 * max(1.0, want.abs().max().item()))
+        _close(dbs[s], seg.sum(0), 3e-5, 3e-5 * max(1.0, M / 64))
+    # accumulation into existing gradients (micro-batches / tied weights): the kernel ADDS
+    if nseg == 1:
+        dw0, db0 = _rand(N, K, seed=5).cuda(), _rand(N, seed=6).cuda()
+        dw1, db1 = dw0.clone(), db0.clone()
+        ops.linear_bwd_weight(dy.cuda(), x.cuda(), 1, N, [True], dw_out=[dw1], db_out=[db1])
+        want = dy.double().t() @ x.double()
+        _close(dw1, dw0.cpu().double() + want, 3e-5, 3e-5 * max(1.0, want.abs().max().item()))
+        _close(db1, db0.cpu().double() + dy.double().sum(0), 3e-5, 3e-5 * max(1.0, M / 64))
+    v4.set_gemm_v4(0)
+    dws0, _ = ops.linear_bwd_weight(dy.cuda(), x.cuda(), nseg, N, [True] * nseg)
+    v4.set_gemm_v4(2)
+    for a, b in zip(dws, dws0):
+        assert (a - b).abs().max().item() <= 3e-5 * max(1.0, b.abs().max().item())

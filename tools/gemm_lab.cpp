@@ -282,6 +282,9 @@ int main(int argc, char** argv) {
         err = do_check ? check(N, K, M, dy, 1, N, x, 1, K, dw, K, nullptr) : -1;
         printf("wgrad M=%5d N=%5d K=%5d nseg=%d %9.1f us %6.1f TF  err %.1e\n", M, n, K, nseg, us, fl / us / 1e6, err);
         timeline("wgrad", [&] { vb_linear_bwd_weight(nullptr, &wg); });
+        wg.accumulate = 1;
+        v4_ab("wgrad", fl, [&] { vb_linear_bwd_weight(nullptr, &wg); });
+        wg.accumulate = 0;
         tot_f += fl; tot_t += us;
         if (getenv("LAB_SPLIT")) {
             // forward as ONE launch over M rows vs TWO launches over M / 2 rows each on two streams (micro-batch halves)

@@ -4,7 +4,7 @@
 //   -DVB_V2_LAYOUT=2  wgrad    (TN)  A row-contiguous, B row-contiguous
 // Each object instantiates the tile menu {64x64, 96x96, 96x128, 128x96, 128x128} (block tile = 32 TM x 32 TN) and the
 // mixed-height launches {128 | 96} x {128, 96}, {96 | 64} x {128, 96}.
-#include "gemm_v4.h"
+#include "gemm_v4w.h"
 
 #ifndef VB_V2_LAYOUT
 #error "compile with -DVB_V2_LAYOUT=0|1|2"
@@ -109,6 +109,14 @@ int launch_v4(hipStream_t st, GemmP p) {
 }
 #endif
 
+#if VB_V2_LAYOUT == 2
+// persistent weight-gradient kernel (gemm_v4w.h): 384 x 96 tiles x K splits as work units
+__global__ __launch_bounds__(V4_THREADS, 4) void gemm_v4w_kernel(const GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_block_v4w<4, 3>(p, smem);
+}
+#endif
+
 int dispatch(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) {
     const int code = tm1 * 100 + tm2 * 10 + tn;
     switch (code) {
@@ -128,6 +136,18 @@ int dispatch(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles
 }  // namespace
 
 namespace vbgemm {
+#if VB_V2_LAYOUT == 2
+int launch_gemm_v4_tn(hipStream_t st, const GemmP& p) {
+    using Cfg = V4WCfg<4, 3>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4w_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    const int grid = p.n_big < 256 ? p.n_big : 256;
+    hipLaunchKernelGGL(gemm_v4w_kernel, dim3(grid), dim3(V4_THREADS), Cfg::LDS_BYTES, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+#endif
 #if VB_V2_LAYOUT == 0
 int launch_gemm_v4_nt(hipStream_t st, const GemmP& p, int tn) { return tn == 3 ? launch_v4<3>(st, p) : launch_v4<4>(st, p); }
 #elif VB_V2_LAYOUT == 1
