@@ -145,3 +145,69 @@ def test_ddp_gradient_after_bucket_launch_is_loud():
             late(x, 1).backward()
     finally:
         dist.destroy_process_group()
+
+
+def test_ddp_foreign_head_gradients_survive_the_arena_fill():
+    """Round-2 advisor (high): a plain torch head on top of a native body hands its gradient to the wrapper BEFORE the
+    first native claim() of the pass; from the second step on (zero_grad(set_to_none=True) -> no slice is owned) the
+    arena fill of that first claim used to wipe the copied slice, and the head trained on zeros. The wrapper now begins
+    the arena's pass before it copies. Three steps, head and body gradients against plain autograd."""
+
+    class Body(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(torch.randn(5, 4))
+
+        def forward(self, x):
+            return ToyLinear.apply(x, self.w)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body, self.head = Body(), nn.Linear(5, 2)       # head = foreign (plain torch) autograd nodes
+
+        def forward(self, x):
+            return self.head(torch.tanh(self.body(x))).pow(2).mean()
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from vilbert.distributed import DistributedDataParallel as DDP
+        torch.manual_seed(3)
+        net = Net()
+        ref = Net()
+        ref.load_state_dict(net.state_dict())
+        ddp = DDP(net, message_size=10 ** 9)
+        x = torch.randn(6, 4)
+        for step in range(3):
+            ddp.zero_grad()                       # set_to_none=True
+            ddp(x).backward()
+            ref.zero_grad()
+            h = torch.tanh(x @ ref.body.w.t())
+            ref.head(h).pow(2).mean().backward()
+            for (n, p), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+                assert p.grad is not None and torch.allclose(p.grad, r.grad, atol=1e-6), (step, n, p.grad, r.grad)
+                assert p.grad.abs().max() > 0, (step, n)
+            with torch.no_grad():
+                for p, r in zip(net.parameters(), ref.parameters()):
+                    p -= 0.1 * p.grad
+                    r -= 0.1 * r.grad
+        ddp.arena.release()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_registry_does_not_keep_arenas_alive():
+    """Round-2 advisor (low): the pointer registry holds arenas weakly - dropping the owner frees the gradient buffer."""
+    import gc
+    import weakref
+    w = nn.Parameter(torch.randn(3, 3))
+    ar = A.GradArena([w])
+    ref = weakref.ref(ar)
+    assert A.lookup(w)[0] is ar
+    del ar
+    gc.collect()
+    assert ref() is None and A.lookup(w) is None

@@ -209,3 +209,77 @@ def test_graphed_step_in_fp8_mode_requantises_the_weights_every_replay():
     finally:
         _native.set_gemm_mode(prev)
         V._drop_p = orig
+
+
+def test_dropped_step_unregisters_its_counter_and_restores_the_exact_gather():
+    """Round-2 advisor: a GraphedTrainStep that is dropped without close() must not leave the process-global dropout
+    step counter pointing at its (freed) device memory, nor the model on the capped label gather. The finaliser runs at
+    garbage collection, close() and the end of a with-block; a newer step's registration is left alone."""
+    import gc
+
+    from vilbert import graphed as G
+    from vilbert.optim import AdamW
+    cfg = synth.tiny_config()
+    sd = synth.make_state_dict(cfg, "pretraining")
+    args = _batches(cfg, 1)[0]
+    m = _model(cfg, sd)
+    opt = AdamW(m.parameters(), lr=0.0)
+    step = G.GraphedTrainStep(m, opt, args, warmup=1)
+    assert G._ACTIVE["epoch_ptr"] == step.epoch.data_ptr() and m.label_capacity == 0.25
+    del step
+    gc.collect()
+    assert G._ACTIVE["epoch_ptr"] is None and m.label_capacity is None
+    with G.GraphedTrainStep(m, opt, args, warmup=1) as s1:
+        s2 = G.GraphedTrainStep(m, opt, args, warmup=1)         # a newer registration ...
+        p2 = s2.epoch.data_ptr()
+    assert G._ACTIVE["epoch_ptr"] == p2                           # ... survives the older step's exit
+    s2.close()
+    assert G._ACTIVE["epoch_ptr"] is None
+
+
+def test_capacity_overflow_is_raised_by_the_next_replay_and_the_divisor_counts_used_rows():
+    """Round-2 advisor: rows beyond the gather capacity used to be dropped silently while the KL divisor still counted
+    all of them. Now the divisor is the number of rows used and the next call of the graphed step raises."""
+    import vilbert.vilbert as V
+    from vilbert.graphed import GraphedTrainStep
+    from vilbert.optim import AdamW
+    cfg = synth.tiny_config()
+    sd = synth.make_state_dict(cfg, "pretraining")
+    args = _batches(cfg, 1)[0]
+    orig_drop, V._drop_p = V._drop_p, (lambda m: 0.0)
+    cap0 = V._capacity
+    try:
+        n_r = int((args[7] == 1).sum().item())
+        assert n_r > 3
+        m = _model(cfg, sd)
+        m.label_capacity = 0.5
+        V._capacity = lambda positions, frac: 3          # fewer slots than labelled rows / tokens
+        img_capped = m(*args)[1].item()
+        with pytest.raises(RuntimeError, match="capacity"):
+            m.check_label_capacity()
+        # exact loss over the same first three labelled regions: label every other region -1
+        lab = args[7].clone().reshape(-1)
+        idx = torch.nonzero(lab == 1).squeeze(1)
+        lab[idx[3:]] = -1
+        m2 = _model(cfg, sd)
+        V._capacity = cap0
+        a2 = list(args)
+        a2[7] = lab.view_as(args[7])
+        assert m2(*a2)[1].item() == pytest.approx(img_capped, rel=1e-5)
+        # graphed: the overflow of a step (here already of the warm-up steps on the example batch) is raised by the next
+        # call - the flag travels to a pinned host word inside the captured graph, no extra synchronisation
+        V._capacity = lambda positions, frac: 3
+        m3 = _model(cfg, sd)
+        step = GraphedTrainStep(m3, AdamW(m3.parameters(), lr=0.0), args, warmup=1)
+        with pytest.raises(RuntimeError, match="capacity"):
+            step(*args)
+        step.close()
+        # with enough capacity nothing is raised
+        V._capacity = cap0
+        m4 = _model(cfg, sd)
+        with GraphedTrainStep(m4, AdamW(m4.parameters(), lr=0.0), args, warmup=1) as ok:
+            ok(*args)
+            ok(*args)
+    finally:
+        V._capacity = cap0
+        V._drop_p = orig_drop

@@ -21,6 +21,8 @@ back-propagated, default = sum of the means of the three pre-training losses as 
     for batch in loader:
         loss = step(*batch)          # copies the batch into the static inputs, replays the graph
 """
+import weakref
+
 import torch
 
 from . import _native as N
@@ -30,14 +32,34 @@ def _default_loss(outputs):
     return sum(o.mean() for o in outputs[:3])
 
 
+_ACTIVE = {"epoch_ptr": None}      # the device counter currently registered with vb_set_seed_epoch by this module
+
+
+def _release(base, prev_capacity, epoch_ptr):
+    """Finaliser of a GraphedTrainStep (close(), garbage collection or the end of a with-block): the process-global
+    dropout step counter must not keep pointing at this step's device memory (every later dropout launch of the process
+    would read a freed / recycled address, and forward / backward masks of one step could then disagree), and the model
+    goes back to the exact (host-synchronising) label gather."""
+    if _ACTIVE["epoch_ptr"] == epoch_ptr:      # (a newer step may have registered its own counter since)
+        N.lib().vb_set_seed_epoch(None)
+        _ACTIVE["epoch_ptr"] = None
+    if base is not None and hasattr(base, "label_capacity"):
+        base.label_capacity = prev_capacity
+
+
 class GraphedTrainStep(object):
-    def __init__(self, model, optimizer, example_inputs, loss_fn=None, label_capacity=0.25, warmup=3):
+    """``with GraphedTrainStep(model, opt, batch) as step: ...`` or ``step.close()`` when done; a step that is simply
+    dropped is cleaned up by its finaliser."""
+
+    def __init__(self, model, optimizer, example_inputs, loss_fn=None, label_capacity=0.25, warmup=3, check_every=1):
         self.model, self.opt = model, optimizer
         self.loss_fn = loss_fn or _default_loss
         base = model.module if hasattr(model, "module") else model
+        prev_capacity = getattr(base, "label_capacity", None)
         if hasattr(base, "label_capacity"):
             base.label_capacity = label_capacity
         self._base = base
+        self.check_every = max(0, int(check_every))
         dev = example_inputs[0].device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs HIP-device inputs - no CPU fallback")
@@ -45,6 +67,12 @@ class GraphedTrainStep(object):
         # device step counter of the dropout masks
         self.epoch = torch.zeros(1, dtype=torch.int64, device=dev)
         N.check(N.lib().vb_set_seed_epoch(self.epoch.data_ptr()), "vb_set_seed_epoch")
+        _ACTIVE["epoch_ptr"] = self.epoch.data_ptr()
+        # the finaliser must not reference self (it would never run); the epoch tensor is kept alive by self only, so
+        # the registration is dropped no later than the memory it points to
+        self._finalizer = weakref.finalize(self, _release, base, prev_capacity, self.epoch.data_ptr())
+        # overflow flag of the fixed-capacity label gather: a pinned host word the captured graph refreshes every replay
+        self._overflow_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         # Warm-up and capture must not train: parameters and optimizer state are snapshotted here and restored after
         # the capture (the warm-up steps are real eager steps on the example batch; the capture itself executes nothing
         # on the device but advances the host-side step counts).
@@ -94,6 +122,9 @@ class GraphedTrainStep(object):
         N.check(N.lib().vb_bump_counter(N.stream_ptr(), self.epoch.data_ptr()), "vb_bump_counter")
         self.opt.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model(*self.static))
+        flag = getattr(self._base, "_label_overflow", None)
+        if flag is not None:
+            self._overflow_host.copy_(flag, non_blocking=True)   # (a D2H copy node inside the captured graph)
         loss.backward()
         self.opt.step()
         return loss
@@ -103,6 +134,12 @@ class GraphedTrainStep(object):
             raise RuntimeError("GraphedTrainStep: expected %d inputs" % len(self.static))
         # the previous replay must be done with the optimizer's pinned table before the host rewrites it
         torch.cuda.current_stream().synchronize()
+        # ... which also makes the previous step's overflow word valid: dropped label rows would bias the losses, so
+        # this is checked by default (check_every=1 costs one host read, no device work); 0 = never
+        if self.check_every and self.replays % self.check_every == 0 and int(self._overflow_host[0]) != 0:
+            raise RuntimeError("GraphedTrainStep: the labelled rows of the previous batch exceeded the fixed gather "
+                               "capacity (label_capacity=%s of the positions) - rows were dropped; construct the step "
+                               "with a larger label_capacity" % (self._base.label_capacity,))
         for s, t in zip(self.static, inputs):
             if torch.is_tensor(s) and s.data_ptr() != t.data_ptr():
                 if s.shape != t.shape or s.dtype != t.dtype:
@@ -120,9 +157,14 @@ class GraphedTrainStep(object):
             self._base.check_label_capacity()
 
     def close(self):
-        N.check(N.lib().vb_set_seed_epoch(None), "vb_set_seed_epoch")
-        if hasattr(self._base, "label_capacity"):
-            self._base.label_capacity = None
+        self._finalizer()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 class GraphedForward(object):

@@ -896,6 +896,7 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         # fixed-capacity gather of that share of the token / region positions (see _losses_at_labelled_positions)
         self.label_capacity = None
         self._label_counts = None
+        self._label_overflow = None     # device flag: a fixed-capacity label gather dropped rows (sticky until checked)
         self.loss_fct = CrossEntropyLoss(ignore_index=-1)
         print("model's visual target is ", config.visual_target)
         if self.visual_target == 0:
@@ -980,7 +981,13 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
             n_r = mask_r.sum()
             valid_r = torch.arange(cap_r, device=idx_r.device) < n_r
             self._label_counts = (n_t, n_r, cap_t, cap_r)
-            divisor_r = n_r.to(torch.float32).reshape(1)
+            # rows beyond the capacity are dropped by the gather: the divisor counts the rows actually used (so the
+            # region loss stays the mean over them instead of being scaled down), and a device-side sticky flag records
+            # the overflow (GraphedTrainStep reads it after every replay, check_label_capacity() on demand)
+            if self._label_overflow is None or self._label_overflow.device != n_t.device:
+                self._label_overflow = torch.zeros(1, dtype=torch.int32, device=n_t.device)
+            self._label_overflow.logical_or_(((n_t > cap_t) | (n_r > cap_r)).reshape(1))
+            divisor_r = torch.clamp(n_r, max=cap_r).to(torch.float32).reshape(1)
         else:
             idx_t = torch.nonzero(lm_flat != -1).squeeze(1)
             idx_r = torch.nonzero(labelled.reshape(-1)).squeeze(1)      # index into [B, n_reg_all - 1]
@@ -1018,6 +1025,10 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         """Raises if the last fixed-capacity label gather overflowed (synchronises; call it off the hot path)."""
         if self._label_counts is None:
             return
+        if self._label_overflow is not None and int(self._label_overflow.item()) != 0:
+            self._label_overflow.zero_()
+            raise RuntimeError("labelled rows exceeded the fixed gather capacity in an earlier step: raise "
+                               "model.label_capacity (fraction of positions, <= 1.0)")
         n_t, n_r, cap_t, cap_r = self._label_counts
         n_t, n_r = int(n_t.item()), int(n_r.item())
         if n_t > cap_t or n_r > cap_r:
