@@ -8,7 +8,7 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "util:SQ_VALU_MFMA_BUSY_CYCLES
   tag=${pass%%:*}; ctr=${pass#*:}
   d=$R/gpurun_out/${name}_$tag
   rm -rf $d
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d $d --output-format csv -- $R/tools/gemm_lab nocheck > $d.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr -d $d --output-format csv -- $R/tools/${LAB_BIN:-gemm_lab_prod} nocheck > $d.log 2>&1
   python3 $R/tools/pmc_summary.py $d gemm > $R/gpurun_out/${name}_$tag.txt
   rm -rf $d $d.log
   wc -l $R/gpurun_out/${name}_$tag.txt

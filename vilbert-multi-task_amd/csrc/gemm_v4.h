@@ -60,6 +60,22 @@ __device__ __forceinline__ void v4_glds16(unsigned off, const float* base, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
 }
 
+// (row, column) of output tile `t`. The 32 tiles an XCD works on at any time (v4_tile_of) should share as few A / W
+// panels as possible: where the tile grid allows it they form a 4 x 8 patch (4 A panels + 8 W panels per XCD and round
+// instead of 1.3 + 24 for a 24-column grid walked row by row: measured 7.0x -> see profiles/r03_gemm_pmc_table.txt for
+// the operand bytes fetched through the fabric per launch); other grids are walked row by row (N fastest).
+__device__ __forceinline__ void v4_tile_rc(int t, int tiles, int tiles_n, int& r, int& c) {
+    const int tiles_m = tiles / tiles_n;
+    if ((tiles_n & 7) == 0 && (tiles_m & 3) == 0) {
+        const int patch = t >> 5, w = t & 31, pcols = tiles_n >> 3;
+        r = (patch / pcols) * 4 + (w >> 3);
+        c = (patch % pcols) * 8 + (w & 7);
+    } else {
+        r = t / tiles_n;
+        c = t % tiles_n;
+    }
+}
+
 template <int TM, int TN, bool B_KC>
 __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, const int lane, const int nk,
                                           const int tiles, const int rounds) {
@@ -72,7 +88,9 @@ __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, c
     int b_seg = 0, b_krem = 0, n0_cur = 0;
     // source addressing of one output tile (A rows clamped to the matrix: rows past M are computed but never stored)
     auto set_tile = [&](int tile) {
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+        int tr, tc;
+        v4_tile_rc(tile, tiles, p.tiles_n, tr, tc);
+        const int m0 = tr * BM, n0 = tc * BN;
         abase = p.A + (long)m0 * p.lda;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -312,8 +330,9 @@ __device__ __forceinline__ void gemm_block_v4(const GemmP& p, float* __restrict_
         asm volatile("v_mov_b32 %0, %1" : "=v"(tid2) : "v"(threadIdx.x));
         const int lane = tid2 & 63, l15 = lane & 15, g = lane >> 4, w2 = tid2 >> 6;
         const int wm = w2 >> 1, wn = w2 & 1;
-        const int tile = v4_tile_of(b, it, grid, tiles);
-        const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+        int tr, tc;
+        v4_tile_rc(v4_tile_of(b, it, grid, tiles), tiles, p.tiles_n, tr, tc);
+        const int m0 = tr * BM, n0 = tc * BN;
         const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
         float* cbase = p.C[0];
         const int row0 = m0 + wm * 16 * TM + l15, col0 = n0 + wn * 16 * TN + 4 * g;

@@ -38,6 +38,7 @@ class _Bucket(object):
         self.hi = arena.offsets[last - 1] + (arena.params[last - 1].numel() + 3) // 4 * 4
         self.flat = arena.flat[self.lo:self.hi]
         self.expected = None     # set of parameter indices that received a gradient in the previous pass
+        self.index = -1          # position in the wrapper's bucket list (launch order = reverse registration order)
         self.reset()
 
     def reset(self):
@@ -82,6 +83,11 @@ class DistributedDataParallel(nn.Module):
                 first, elems = i + 1, 0
         if first < len(self.arena.params):
             self._buckets.append(_Bucket(self.arena, first, len(self.arena.params)))
+        for k, b in enumerate(self._buckets):
+            b.index = k
+        # measurement hook (bench.py comm_model): a list here receives (bucket index, bytes, timing event recorded on the
+        # launching stream at the moment the bucket's all-reduce is enqueued) for every launch
+        self.trace = None
         self._where = {}
         for b in self._buckets:
             for i in range(b.first, b.last):
@@ -141,6 +147,10 @@ class DistributedDataParallel(nn.Module):
             for handle, st in b.streams.items():
                 if handle != cur.cuda_stream:
                     cur.wait_stream(st)
+        if self.trace is not None and b.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((b.index, b.flat.numel() * b.flat.element_size(), ev))
         op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
         b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
         b.launched = True
