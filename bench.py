@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0, help="GLOBAL batch divided over the ranks (strong scaling; the "
                     "reference's own data-parallel mode, train_concap.py:290-294) instead of a fixed per-GPU batch")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the global512 / fwd_b512 legs of the default line")
+    ap.add_argument("--deterministic", action="store_true", help="deterministic split-K weight gradients "
+                    "(vb_set_deterministic: workspace + ordered reduce instead of atomics; single stream)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even at world size 1 "
                     "(exercises the RCCL bucket path on a single GPU)")
     args = ap.parse_args()
@@ -217,6 +219,8 @@ def main():
     from vilbert import _native, ops
     from vilbert.vilbert import BertConfig
     _native.set_gemm_mode(args.gemm_mode)
+    if args.deterministic:
+        _native.set_deterministic(True, device=device)
     CONFIG, N_TOK, N_REG = args.config, args.tokens, args.regions
     cfg = BertConfig.from_json_file(os.path.join(ROOT, "vilbert-multi-task_amd", "config", CONFIG)).to_dict()
     B = args.batch
@@ -692,6 +696,7 @@ def main():
                          "flops_per_launch_avg": round(gemm_flops / max(gemm_launches, 1), 0)},
         }
         line["config"]["gemm_mode"] = args.gemm_mode
+        line["config"]["deterministic_wgrad"] = bool(args.deterministic)
         line.update(extra)
         if alt:
             line["alt_gemm_modes"] = alt

@@ -29,13 +29,14 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 10
+#define VB_ABI_VERSION 11
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
 #define VB_E_ALIGN    (-2)  /* pointer or leading dimension not usable by the kernel */
 #define VB_E_RANGE    (-3)  /* size outside the compiled range (e.g. keys > VB_MAX_KEYS) */
 #define VB_E_SEGMENT  (-4)  /* bad weight-segment description */
+#define VB_E_WORKSPACE (-5) /* deterministic mode: the registered workspace is too small for this launch */
 
 /* epilogue activations of vb_linear_fwd */
 #define VB_ACT_NONE 0
@@ -77,6 +78,19 @@ int vb_bump_counter(void* stream, uint64_t* device_counter);   /* *device_counte
  * {434, 433, 324, 323} = force that mixed-height pair, -1 = round-1 kernel only.
  * Returns the previous code; an unknown value only queries. Environment: VB_GEMM_TILE=<code>, VB_GEMM_V2=0. */
 int vb_set_gemm_tile(int code);
+
+/* Deterministic weight gradients (round 3). By default a split-K launch (vb_linear_bwd_weight: the contraction runs
+ * over the token rows; vb_linear_bwd_input with a small output and a long contraction, e.g. the MLM decoder) adds the
+ * partial products of its splits into the result with fp32 atomics: the value depends in the last bits on the order the
+ * blocks finish in, where the reference's cuBLAS path (autograd of the nn.Linear call sites, vilbert.py:425-427, 471,
+ * 501, 514) is repeatable. With on = 1 every split stores its partial product into `workspace` and a second kernel
+ * adds the partials in split order: bit-identical from run to run (measured cost: DESIGN.md). The workspace (device
+ * memory, 16-byte aligned, owned by the caller, must outlive the setting) is cut into 8 equal slices, one per stream
+ * that issues split launches (so launches on different streams never share memory); a slice has to hold
+ * splits x (M x N + M) floats of the largest split launch (8 x 256 MiB is ample for the two-stream models), else - or when
+ * a ninth stream shows up - the launch returns VB_E_WORKSPACE. The embedding-table gradients (vb_text_embed_bwd) still
+ * use atomics. Returns the previous setting (0 / 1) or a negative error. */
+int vb_set_deterministic(int on, void* workspace, int64_t workspace_bytes);
 
 /* Persistent one-block-per-CU fp32 GEMM (round 3; forward and dgrad layouts of vb_linear_fwd / vb_linear_bwd_input,
  * replaces the same nn.Linear call sites - vilbert.py:425-427,471,501,514): 12 MFMA waves + 1 LDS-DMA loader wave per

@@ -78,7 +78,7 @@ def test_dropout_mask_is_a_function_of_seed_and_index(ops):
     assert torch.allclose(ops.dropout(g, 0.1, 1234, r), g * y1 + r, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("rows,cols", [(37, 64), (300, 768), (129, 1024), (5, 2048)])
+@pytest.mark.parametrize("rows,cols", [(37, 64), (300, 768), (129, 1024), (5, 2048), (9, 4096), (7, 8192), (6, 5000)])
 def test_layernorm_backward(ops, rows, cols):
     x, dy = _rand(rows, cols, seed=1, scale=2.0) + 0.3, _rand(rows, cols, seed=2)
     g, b = 1 + 0.1 * _rand(cols, seed=3), 0.1 * _rand(cols, seed=4)

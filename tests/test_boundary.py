@@ -112,3 +112,36 @@ def test_from_pretrained(tmp_path):
     bare = {k[len("bert."):]: v for k, v in sd.items() if k.startswith("bert.")}
     m2 = BertForMultiModalPreTraining.from_pretrained(str(tmp_path), config=config, state_dict=bare)
     assert torch.equal(m2.bert.t_pooler.dense.weight, sd["bert.t_pooler.dense.weight"])
+
+
+def test_constructor_and_forward_signatures_equal_the_reference():
+    """Drop-in boundary (round-2 verdict, harness item 13): every public class of the hot path has the reference's
+    ``__init__`` and ``forward`` signature - parameter names, order, kinds and defaults - compared with
+    inspect.signature against the REAL reference classes (build container only; the GPU box has no reference tree)."""
+    import inspect
+    if not ref_loader.available():
+        pytest.skip("reference tree not present")
+    ref = ref_loader.load()
+    import vilbert.vilbert as ours
+    names = ["BertConfig", "BertEmbeddings", "BertImageEmbeddings", "BertSelfAttention", "BertSelfOutput", "BertAttention",
+             "BertIntermediate", "BertOutput", "BertLayer", "BertImageSelfAttention", "BertImageSelfOutput",
+             "BertImageAttention", "BertImageIntermediate", "BertImageOutput", "BertImageLayer", "BertBiAttention",
+             "BertBiOutput", "BertConnectionLayer", "BertEncoder", "BertTextPooler", "BertImagePooler", "BertModel",
+             "BertPreTrainingHeads", "BertForMultiModalPreTraining", "VILBertForVLTasks", "SimpleClassifier"]
+    checked = 0
+    for name in names:
+        theirs, mine = getattr(ref, name, None), getattr(ours, name, None)
+        if theirs is None:
+            continue
+        assert mine is not None, "missing class " + name
+        for meth in ("__init__", "forward"):
+            if not hasattr(theirs, meth) or getattr(theirs, meth) is getattr(object, meth, None):
+                continue
+            st, sm = inspect.signature(getattr(theirs, meth)), inspect.signature(getattr(mine, meth))
+            got = [(p.name, p.kind, p.default) for p in sm.parameters.values()]
+            want = [(p.name, p.kind, p.default) for p in st.parameters.values()]
+            assert got == want, "%s.%s: %s != reference %s" % (name, meth, sm, st)
+            checked += 1
+    assert checked >= 40
+    for fn in ("from_dict", "from_json_file", "to_dict", "to_json_string"):
+        assert str(inspect.signature(getattr(ours.BertConfig, fn))) == str(inspect.signature(getattr(ref.BertConfig, fn)))

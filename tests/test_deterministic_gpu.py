@@ -1,0 +1,130 @@
+"""Deterministic split-K weight gradients (vb_set_deterministic, round-2 verdict missing item 6): partial products of the
+K splits go to a workspace and are added in split order instead of with fp32 atomics. Two runs must be BIT-identical
+(they are not required to be with atomics), the values must agree with the atomic path and with fp64, a workspace that
+is too small must be refused loudly."""
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def det():
+    from vilbert import _native
+    wanted = _native._DET["wanted"]           # (on by default; registered lazily at the first split launch)
+    _native.set_deterministic(True)
+    yield _native
+    _native.set_deterministic(wanted)
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# token rows, out-features per segment, in-features, segments: 4-wave kernel with several splits (768 x 768 at 9216 rows,
+# the q | k | v stack, a ragged-row image-stream shape), the persistent kernel (FFN weights: 64 tiles x 4 splits)
+@pytest.mark.parametrize("M,N,K,nseg", [(9216, 768, 768, 1), (9216, 768, 768, 3), (9472, 1024, 1024, 1), (9216, 3072, 768, 1),
+                                        (9216, 768, 3072, 1), (1000, 256, 128, 1)])
+def test_weight_gradient_is_bit_identical_and_correct(det, M, N, K, nseg):
+    from vilbert import ops
+    x, dy = _rand(M, K, seed=1).to(DEV), _rand(M, nseg * N, seed=2).to(DEV)
+    runs = []
+    for _ in range(3):
+        dws, dbs = ops.linear_bwd_weight(dy, x, nseg, N, [True] * nseg)
+        runs.append([t.clone() for t in dws + dbs])
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b), "deterministic mode gave different bits in two runs"
+    for s in range(nseg):
+        seg = dy[:, s * N:(s + 1) * N].double()
+        want = (seg.t() @ x.double()).cpu()
+        err = (runs[0][s].cpu().double() - want).abs().max().item()
+        assert err <= 3e-5 * max(1.0, want.abs().max().item()), err
+        wb = seg.sum(0).cpu()
+        assert (runs[0][nseg + s].cpu().double() - wb).abs().max().item() <= 3e-5 * max(1.0, M / 64)
+    # accumulation into an existing gradient
+    g0 = _rand(N, K, seed=3).to(DEV)
+    g1 = g0.clone()
+    ops.linear_bwd_weight(dy[:, :N].contiguous(), x, 1, N, [False], dw_out=[g1])
+    want = g0.cpu().double() + (dy[:, :N].double().t() @ x.double()).cpu()
+    assert (g1.cpu().double() - want).abs().max().item() <= 3e-5 * max(1.0, want.abs().max().item())
+    # same values as the atomic path up to summation order
+    det.set_deterministic(False)
+    dws0, _ = ops.linear_bwd_weight(dy, x, nseg, N, [True] * nseg)
+    det.set_deterministic(True)
+    for a, b in zip(runs[0][:nseg], dws0):
+        assert (a - b).abs().max().item() <= 3e-5 * max(1.0, b.abs().max().item())
+
+
+def test_split_k_dgrad_of_a_small_output_is_bit_identical(det):
+    """vb_linear_bwd_input splits a long contraction over a small output (the MLM decoder: dX[rows, 768] over 30522
+    out-features) - same mechanism."""
+    from vilbert import ops
+    dy, w = _rand(1628, 30522, seed=4, scale=0.1).to(DEV), _rand(30522, 768, seed=5, scale=0.05).to(DEV)
+    a = ops.linear_bwd_input(dy, [w], 768)
+    b = ops.linear_bwd_input(dy, [w], 768)
+    assert torch.equal(a, b)
+    want = (dy.double() @ w.double()).cpu()
+    assert (a.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_workspace_too_small_is_refused():
+    from vilbert import _native, ops
+    prev = _native._DET["wanted"]
+    _native.set_deterministic(False)
+    ws = torch.empty(8 * 1024, dtype=torch.float32, device=DEV)
+    assert _native.lib().vb_set_deterministic(1, ws.data_ptr(), ws.numel() * 4) == 0
+    try:
+        x, dy = _rand(9216, 768, seed=1).to(DEV), _rand(9216, 768, seed=2).to(DEV)
+        with pytest.raises(RuntimeError, match="WORKSPACE"):
+            ops.linear_bwd_weight(dy, x, 1, 768, [True])
+    finally:
+        _native.lib().vb_set_deterministic(0, None, 0)
+        _native.set_deterministic(prev)
+
+
+def test_default_is_deterministic_and_streams_stay_on():
+    """The setting is on by default (VB_DETERMINISTIC unset) and keeps the two-stream overlap and the weight-gradient side
+    streams (every stream has its own workspace slice)."""
+    import vilbert.vilbert as V
+    from vilbert import _native, autograd_ops as AO
+    assert _native._DET["wanted"] is True
+    assert V._TWO_STREAMS and AO._WGRAD["on"]
+
+
+def test_model_gradients_bit_identical_except_embedding_tables(det):
+    """Two backward passes of the 2L/2C pre-training model on the same batch: every gradient produced by a GEMM (weights,
+    biases) and by the LayerNorm / attention kernels is bit-identical; the embedding tables (scatter with atomics) are
+    excluded, as documented in include/vilbert_hip.h."""
+    import vilbert.vilbert as V
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    sd = synth.make_state_dict(cfg, "pretraining")
+    x = synth.make_inputs(cfg, 32, 36, 37, with_labels=True)
+    names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+             "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
+    args = [x[n].to(DEV) for n in names]
+    orig, V._drop_p = V._drop_p, (lambda m: 0.0)
+    try:
+        m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        grads = []
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            sum(l.mean() for l in m(*args)).backward()
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+        checked = 0
+        for n, g in grads[0].items():
+            if "embeddings.word_embeddings" in n or "position_embeddings" in n or "token_type_embeddings" in n:
+                continue
+            assert torch.equal(g, grads[1][n]), n
+            checked += 1
+        assert checked > 150
+    finally:
+        V._drop_p = orig

@@ -20,6 +20,7 @@ extern "C" const char* vb_error_string(int code) {
         case VB_E_ALIGN: return "VB_E_ALIGN: pointer / leading dimension not 16-byte aligned or size not a multiple of 4";
         case VB_E_RANGE: return "VB_E_RANGE: size outside the compiled range";
         case VB_E_SEGMENT: return "VB_E_SEGMENT: bad weight-segment description";
+        case VB_E_WORKSPACE: return "VB_E_WORKSPACE: deterministic mode - the registered workspace is too small for this launch";
         default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));

@@ -33,6 +33,8 @@
 // of logical tiles (N fastest) and the blocks sharing an A panel share one L2.
 #include <string.h>
 
+#include <mutex>
+
 #include "gemm_v2.h"
 
 namespace {
@@ -409,6 +411,78 @@ int gemm_v4_mode() {
     return g_gemm_v4;
 }
 
+// Deterministic split-K (vb_set_deterministic): the splits of a launch store their partial products to a workspace
+// registered by the caller and splitk_reduce_kernel adds them to C in split order - bit-identical results from run to
+// run, where the default (fp32 atomics from all splits into C) depends on the order the blocks happen to finish in.
+int g_det = -1;
+float* g_det_ws = nullptr;
+size_t g_det_bytes = 0;
+// The workspace is cut into DET_SLICES equal slices; every stream that issues split launches gets its own (first come,
+// first served, for the lifetime of the setting), so the text / image / weight-gradient side streams keep overlapping.
+constexpr int DET_SLICES = 8;
+hipStream_t g_det_streams[DET_SLICES];
+int g_det_nstreams = 0;
+std::mutex g_det_mutex;     // autograd runs backward nodes on its own threads
+
+bool deterministic() {
+    if (g_det < 0) g_det = 0;
+    return g_det != 0 && g_det_ws != nullptr;
+}
+
+// slice of the calling stream, or -1 when more than DET_SLICES streams have asked
+int det_slice_of(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    for (int i = 0; i < g_det_nstreams; ++i)
+        if (g_det_streams[i] == st) return i;
+    if (g_det_nstreams == DET_SLICES) return -1;
+    g_det_streams[g_det_nstreams] = st;
+    return g_det_nstreams++;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ cs_ws,
+                                                            int splits, long stride, int M, int N, GemmP p) {
+    // C[r][c] += sum over the splits (in order) of ws[s][r][c]; bias gradient: colsum[r] += sum of cs_ws[s][r]
+    const long n4 = (long)M * (N / 4);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        const int r = (int)(i / (N / 4)), c = (int)(i % (N / 4)) * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + (long)r * N + c);
+        for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(ws + s * stride + (long)r * N + c);
+        const int sg = r / p.cseg;
+        float* dst = p.C[sg] + (long)(r - sg * p.cseg) * p.ldc + c;
+        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + acc;
+    } else if (cs_ws != nullptr && i - n4 < M) {
+        const int r = (int)(i - n4);
+        float acc = cs_ws[r];
+        for (int s = 1; s < splits; ++s) acc += cs_ws[(long)s * M + r];
+        const int sg = r / p.cseg;
+        p.colsum[sg][r - sg * p.cseg] += acc;
+    }
+}
+
+// Points the launch at the workspace (-> the kernels store partials instead of adding atomically). false = the
+// registered workspace is too small for `splits` partial copies of C.
+bool det_prepare(hipStream_t st, GemmP& p, int splits) {
+    const size_t need = ((size_t)splits * p.M * p.N + (size_t)splits * p.M) * sizeof(float);
+    const size_t slice = g_det_bytes / DET_SLICES / 16 * 16;
+    const int k = det_slice_of(st);
+    if (k < 0 || need > slice) return false;
+    float* base = g_det_ws + (size_t)k * (slice / sizeof(float));
+    p.det_ws = base;
+    p.det_stride = (long)p.M * p.N;
+    p.det_cs = base + (size_t)splits * p.M * p.N;
+    return true;
+}
+
+int det_finish(hipStream_t st, const GemmP& p, int splits) {
+    const bool cs = p.colsum[0] != nullptr;
+    const long work = (long)p.M * (p.N / 4) + (cs ? p.M : 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p.det_ws, cs ? p.det_cs : nullptr,
+                       splits, p.det_stride, p.M, p.N, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
 int plan_v4(const GemmP& p, bool b_kc) {
     const int mode = gemm_v4_mode();
     if (mode == 0) return 0;
@@ -479,7 +553,13 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     // vec_v2: 16-byte loads legal for the second-generation kernel (it tolerates a row-contiguous A whose row count is
     // not a multiple of 4 when the leading dimension leaves room for the last float4); default = same as `vec`
     if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec_v2 < 0 ? vec : vec_v2 != 0, splits, pl)) {
-        if (!A_KC && !B_KC && splits < 0 && plan_v4w(p)) return launch_gemm_v4_tn(st, p);
+        if (!A_KC && !B_KC && splits < 0 && plan_v4w(p)) {
+            const int s4 = p.n_big / p.n_small;
+            const bool det = s4 > 1 && deterministic();
+            if (det && !det_prepare(st, p, s4)) return VB_E_WORKSPACE;
+            if (int e = launch_gemm_v4_tn(st, p)) return e;
+            return det ? det_finish(st, p, s4) : 0;
+        }
         // persistent 288-row tiles (gemm_v4.h) where they fill the chip in whole rounds
         if (A_KC && splits == 1) {
             const int tn4 = plan_v4(p, B_KC);
@@ -491,9 +571,14 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         p.m_split = pl.big_rows * 32 * pl.tm1;
         if (splits < 0) p.epi = pl.splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
         const int tiles = (pl.big_rows + pl.small_rows) * pl.tiles_n;
-        if (A_KC && B_KC) return launch_gemm_v2_nt(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
-        if (A_KC) return launch_gemm_v2_nn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
-        return launch_gemm_v2_tn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
+        const bool det = splits < 0 && pl.splits > 1 && deterministic();
+        if (det && !det_prepare(st, p, pl.splits)) return VB_E_WORKSPACE;
+        int e = 0;
+        if (A_KC && B_KC) e = launch_gemm_v2_nt(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
+        else if (A_KC) e = launch_gemm_v2_nn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
+        else e = launch_gemm_v2_tn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
+        if (e) return e;
+        return det ? det_finish(st, p, pl.splits) : 0;
     }
     // round-1 kernel: any alignment, ragged K, every epilogue. It stores the pre-activation where the activation
     // derivative is wanted and leaves the multiplier to a post-pass (both fused only in the kernel above; keeping
@@ -511,7 +596,7 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         if (p.epi == EPI_MUL) p.epi = EPI_STORE;
     }
     if (splits < 0) {
-        splits = legacy_splits;
+        splits = deterministic() ? 1 : legacy_splits;    // (the round-1 kernel only splits with atomics)
         const int kt_total = (p.K + BK - 1) / BK;
         p.ktiles_per_split = (kt_total + splits - 1) / splits;
         splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
@@ -548,6 +633,18 @@ extern "C" int vb_set_gemm_tile(int code) {
     if (code == -1 || code == 0 || code == 22 || code == 33 || code == 34 || code == 43 || code == 44 || code == 434 ||
         code == 433 || code == 324 || code == 323)
         g_gemm_tile = code;
+    return prev;
+}
+
+extern "C" int vb_set_deterministic(int on, void* workspace, int64_t workspace_bytes) {
+    const int prev = g_det > 0 ? 1 : 0;
+    if (on != 0 && on != 1) return prev;
+    if (on && (workspace == nullptr || workspace_bytes <= 0 || !vb_aligned16(workspace))) return VB_E_BADARG;
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    g_det = on;
+    g_det_nstreams = 0;
+    g_det_ws = on ? static_cast<float*>(workspace) : nullptr;
+    g_det_bytes = on ? (size_t)workspace_bytes : 0;
     return prev;
 }
 

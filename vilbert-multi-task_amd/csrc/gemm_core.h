@@ -40,6 +40,10 @@ struct GemmP {
     uint64_t seed;
     const uint64_t* epoch;     // device step counter mixed into the seed (vb_set_seed_epoch), may be null
     unsigned long long* dbg;   // lab only (vblab_gemm_cycles): block 0 stores its shader-clock span here
+    // deterministic split-K (vb_set_deterministic): split s stores its partial product to det_ws + s * det_stride as a
+    // plain [M, N] matrix (and its bias-gradient partial to det_cs + s * M) instead of adding into C with atomics; a
+    // second kernel sums the partials in split order (splitk_reduce_kernel)
+    float* det_ws; float* det_cs; long det_stride;
 };
 
 // XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).

@@ -446,9 +446,19 @@ __device__ __forceinline__ void gemm_tile_v2(const GemmP& p, float* __restrict__
     // ---- epilogue ----------------------------------------------------------------------------------------------
     const int cs = m0 / p.cseg;                 // C row segment of this tile (tiles never straddle segments)
     const int mloc = m0 - cs * p.cseg;
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
+    if (p.det_ws != nullptr) {
+        // deterministic split-K: this split's partial tile as a plain store into its own [M, N] workspace slice
+        if (want_colsum && m0 + tid < p.M) p.det_cs[(long)blockIdx.y * p.M + m0 + tid] = csum;
+        GemmP q = p;
+        q.ldc = p.N;
+        float* wbase = p.det_ws + (long)blockIdx.y * p.det_stride;
+        if (!A_KC) epilogue_v2_nat<EPI_STORE, TM, TN>(q, wbase, acc, m0 + wm * 16 * TM + 4 * g, n0 + wn * 16 * TN + l15, full);
+        else epilogue_v2<EPI_STORE, TM, TN, false>(q, wbase, acc, m0 + wm * 16 * TM + l15, n0 + wn * 16 * TN + 4 * g, false, full);
+        return;
+    }
     if (want_colsum && mloc + tid < p.cseg && m0 + tid < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + tid, csum);
     const bool lead = blockIdx.y == 0;          // bias / residual are added by one split only
-    const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
     float* cbase = p.C[cs] - (long)cs * p.cseg * p.ldc;   // so that cbase + row * ldc addresses global row `row`
     if (!A_KC) {
         const int r0 = m0 + wm * 16 * TM + 4 * g, c0 = n0 + wn * 16 * TN + l15;

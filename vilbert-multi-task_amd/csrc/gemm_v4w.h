@@ -204,9 +204,16 @@ __device__ __forceinline__ void gemm_block_v4w(const GemmP& p, float* __restrict
         const int wm = w2 >> 1, wn = w2 & 1;
         const int cs = m0 / p.cseg;                 // C row segment (stacked weights: one dW tensor per segment)
         const int mloc = m0 - cs * p.cseg;
+        const int r0 = m0 + wm * 16 * TM + 4 * g, c0 = n0 + wn * 16 * TN + l15;
+        if (p.det_ws != nullptr) {     // deterministic split-K: plain store of the unit's partial into its split's slice
+            if (want_colsum) p.det_cs[(long)split * p.M + m0 + tid2] = csum;
+            GemmP q = p;
+            q.ldc = p.N;
+            epilogue_v2_nat<EPI_STORE, TM, TN>(q, p.det_ws + (long)split * p.det_stride, acc, r0, c0, true);
+            continue;
+        }
         if (want_colsum) unsafeAtomicAdd(p.colsum[cs] + mloc + tid2, csum);
         float* cbase = p.C[cs] - (long)cs * p.cseg * p.ldc;
-        const int r0 = m0 + wm * 16 * TM + 4 * g, c0 = n0 + wn * 16 * TN + l15;
         if (p.epi == EPI_ATOMIC) epilogue_v2_nat<EPI_ATOMIC, TM, TN>(p, cbase, acc, r0, c0, true);
         else epilogue_v2_nat<EPI_ACCUM, TM, TN>(p, cbase, acc, r0, c0, true);
     }

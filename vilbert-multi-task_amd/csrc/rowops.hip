@@ -419,6 +419,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int n_col
     }
 }
 
+// Rows wider than 4096 columns (nothing in the two-stream models; the C ABI allows up to VB_MAX_LN_COLS): one wave per
+// row, the row walked twice in 256-column chunks (pass 1: the two row means, pass 2: dx and this row's dgamma / dbeta
+// terms, written straight to the workspace: one partial per row) - no per-column accumulators in registers, so no
+// scratch (the register-resident variant above spilled 940 bytes per lane at NV = 32).
+__global__ __launch_bounds__(256) void layernorm_bwd_wide_kernel(long rows, int n_cols, const float* __restrict__ dy,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 float* __restrict__ dx, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mu = mean[row], rs = rstd[row];
+    const float* __restrict__ dyr = dy + row * n_cols;
+    const float* __restrict__ xr = x + row * n_cols;
+    float s1 = 0.f, s2 = 0.f;
+    for (int col = lane * 4; col < n_cols; col += 256) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dyr + col);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(xr + col) - mu) * rs;
+        const f32x4 g = d * *reinterpret_cast<const f32x4*>(gamma + col);
+        s1 += (g[0] + g[1]) + (g[2] + g[3]);
+        s2 += (g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3]);
+    }
+    const float m1 = wave_sum(s1) / (float)n_cols, m2 = wave_sum(s2) / (float)n_cols;
+    float* __restrict__ w = ws + row * 2 * n_cols;
+    for (int col = lane * 4; col < n_cols; col += 256) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dyr + col);
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(xr + col) - mu) * rs;
+        const f32x4 g = d * *reinterpret_cast<const f32x4*>(gamma + col);
+        *reinterpret_cast<f32x4*>(dx + row * n_cols + col) = (g - m1 - xh * m2) * rs;
+        *reinterpret_cast<f32x4*>(w + col) = d * xh;
+        *reinterpret_cast<f32x4*>(w + n_cols + col) = d;
+    }
+}
+
 // Column sums of `parts` workspace rows of width 2 * n_cols. Block = 1024 threads = 16 row groups x
 // 64 columns; each group strides over the parts, then an LDS tree over the 16 groups.
 __global__ __launch_bounds__(1024) void colreduce_kernel(long parts, int width, const float* __restrict__ ws,
@@ -518,6 +554,7 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(int batch, int n_tok
 
 extern "C" int64_t vb_layernorm_bwd_workspace(int64_t rows, int32_t n_cols) {
     if (rows <= 0 || n_cols <= 0) return 0;
+    if (nv_for(n_cols) > 16) return rows * 2 * n_cols;   // wide rows: one partial per row (layernorm_bwd_wide_kernel)
     const int64_t parts = (rows + LNB_ROWS_PER_WAVE - 1) / LNB_ROWS_PER_WAVE;
     const int64_t parts_padded = (parts + 3) / 4 * 4;  // whole blocks write
     return parts_padded * 2 * n_cols;
@@ -534,12 +571,25 @@ extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, cons
         return VB_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long blocks = (rows + LNB_ROWS_PER_BLOCK - 1) / LNB_ROWS_PER_BLOCK;
-    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), dim3((unsigned)blocks), dim3(256),
-                                                      0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx,
-                                                      workspace));
-    VB_LAUNCH_CHECK();
     const int width = 2 * n_cols;
-    const long parts = nv_for(n_cols) <= 4 ? blocks : blocks * 4;  // one partial per block / per wave
+    long parts = nv_for(n_cols) <= 4 ? blocks : blocks * 4;  // one partial per block / per wave
+    if (nv_for(n_cols) > 16) {
+        hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (long)rows, n_cols, dy,
+                           x, mean, rstd, gamma, dx, workspace);
+        parts = rows;
+    } else {
+        switch (nv_for(n_cols)) {
+            case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+            case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+            case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+            case 4: hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+            case 5: case 6: case 7: case 8:
+                hipLaunchKernelGGL((layernorm_bwd_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+            default:
+                hipLaunchKernelGGL((layernorm_bwd_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+        }
+    }
+    VB_LAUNCH_CHECK();
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, st, parts, width,
                        workspace, dgamma, dbeta, n_cols);
     VB_LAUNCH_CHECK();

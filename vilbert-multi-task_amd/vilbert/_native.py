@@ -146,6 +146,7 @@ SIGNATURES = {
     "vb_set_gemm_mode": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_gemm_tile": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_gemm_v4": (ctypes.c_int, [ctypes.c_int]),
+    "vb_set_deterministic": (ctypes.c_int, [ctypes.c_int, _P, _I64]),
     "vb_set_seed_epoch": (ctypes.c_int, [_P]),
     "vb_bump_counter": (ctypes.c_int, [_P, _P]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
@@ -189,7 +190,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 10:
+        if handle.vb_abi_version() != 11:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") == "fp8":
@@ -201,6 +202,38 @@ def set_gemm_tile(code):
     """Tile selection of the fp32 GEMM: 0 = cost model, 22 | 33 | 34 | 43 | 44 = force a tile of the
     second-generation kernel, -1 = round-1 kernel only. Returns the previous code."""
     return lib().vb_set_gemm_tile(int(code))
+
+
+_DET = {"workspace": None, "wanted": os.environ.get("VB_DETERMINISTIC", "1") != "0"}
+
+
+def set_deterministic(on, workspace_mb=2048, device=None):
+    """Deterministic split-K weight gradients (include/vilbert_hip.h: vb_set_deterministic): the K splits of a launch
+    store their partial products to a device workspace and a second kernel adds them in split order - bit-identical
+    gradients from run to run, and measured FASTER than the fp32-atomics path (profiles/r03_deterministic_cost.txt), so
+    it is the default (VB_DETERMINISTIC=0 or set_deterministic(False) = atomics). Allocates (once) and registers the
+    workspace (8 per-stream slices of 256 MiB: the largest split launch of the models, the MLM-decoder dgrad at batch 256,
+    needs ~70 MB); returns the previous setting."""
+    import torch
+    if on:
+        ws = _DET["workspace"]
+        if ws is None or ws.numel() * 4 < workspace_mb * (1 << 20):
+            ws = torch.empty(workspace_mb * (1 << 20) // 4, dtype=torch.float32, device=device or "cuda")
+        prev = lib().vb_set_deterministic(1, ws.data_ptr(), ws.numel() * 4)
+        if prev < 0:
+            check(prev, "vb_set_deterministic")
+        _DET["workspace"], _DET["wanted"] = ws, True
+        return bool(prev)
+    prev = lib().vb_set_deterministic(0, None, 0)
+    _DET["workspace"], _DET["wanted"] = None, False
+    return bool(prev)
+
+
+def ensure_deterministic(device):
+    """Called by the split-K launchers: registers the default workspace on first use (the setting is on by default, the
+    allocation needs the device)."""
+    if _DET["wanted"] and _DET["workspace"] is None:
+        set_deterministic(True, device=device)
 
 
 def set_gemm_v4(mode):

@@ -255,6 +255,7 @@ def linear_bwd_input(dy, weights, in_features, residual=None, mul=None):
     """dX = (dY @ cat(weights) + residual) * mul for dY [..., nseg*n]; returns [..., in_features].
     residual: a gradient of the same shape arriving over a skip connection (added in the GEMM epilogue);
     mul: elementwise multiplier of the same shape (the saved activation derivative of the producing layer)."""
+    N.ensure_deterministic(dy.device)
     nseg, seg_n = len(weights), weights[0].shape[0]
     ldy = nseg * seg_n
     if _row_strided(dy) and dy.shape[1] == ldy:
@@ -292,6 +293,7 @@ def linear_bwd_weight(dy, x, nseg, seg_n, want_bias, dw_out=None, db_out=None):
     per-segment target tensors (gradient-arena slices: zero-filled once per backward pass, or holding an earlier
     contribution) or None; the targets not given are slices of ONE zero-filled buffer allocated here (one fill
     launch instead of two per segment)."""
+    N.ensure_deterministic(dy.device)
     ldy = nseg * seg_n
     if _row_strided(dy) and dy.shape[1] == ldy:
         ldy = dy.stride(0)
