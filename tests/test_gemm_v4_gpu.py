@@ -125,7 +125,10 @@ def test_planner_picks_the_persistent_kernel_only_where_it_fills_the_chip(ops):
 # step (W[768, 768]: 16 tiles x 16 splits = 256 units; W[3072, 768] / W[768, 3072]: 64 tiles x 4 splits); several
 # rounds of units per block (2 tiles x 8 col tiles x 18 splits = 288 units)
 WGRAD_SHAPES = [(256, 384, 96, 1), (512, 384, 192, 1), (1152, 384, 96, 3), (9216, 768, 768, 1), (9216, 3072, 768, 1),
-                (2304, 768, 3072, 1), (9216, 768, 768, 3), (4608, 768, 384, 1)]
+                (2304, 768, 3072, 1), (9216, 768, 768, 3), (4608, 768, 384, 1),
+                # 256-row tiles on 8 MFMA waves (1024 / 4096-row weights: image stream, connection layers, bert_large)
+                (512, 256, 128, 1), (9216, 1024, 1024, 1), (9472, 1024, 1024, 1), (2304, 1024, 768, 3), (4608, 4096, 1024, 1),
+                (4608, 1024, 4096, 1)]
 
 
 @pytest.mark.parametrize("M,N,K,nseg", WGRAD_SHAPES)

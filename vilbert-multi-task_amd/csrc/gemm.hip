@@ -509,35 +509,42 @@ int plan_v4(const GemmP& p, bool b_kc) {
 // Persistent weight-gradient kernel (gemm_v4w.h): 384 x 96 tiles of dW times K splits as equal work units. Fills the
 // launch fields and returns true when the shape divides (text-stream weights: 768 / 2304 / 3072 rows, 768 / 3072
 // columns) and the units fill the chip.
-bool plan_v4w(GemmP& p) {
+int plan_v4w(GemmP& p) {
     const int mode = gemm_v4_mode();
-    if (mode == 0) return false;
-    constexpr int BM = 384, BN = 96;
-    if (p.M % BM != 0 || p.N % BN != 0 || p.K % 32 != 0 || p.cseg % BM != 0) return false;
+    if (mode == 0 || p.K % 32 != 0) return -1;
+    // {tile rows, tile columns, relative main-loop efficiency}: 12 MFMA waves for the 384-row tiles, 8 for the 256-row ones
+    static const struct { int bm, bn; double eff; } cfgs[3] = {{384, 96, 1.0}, {256, 128, 0.95}, {256, 96, 0.93}};
     const int kt = p.K / V2_BK;
-    const long tiles = (long)(p.M / BM) * (p.N / BN);
     double best = 1e300;
-    int best_s = 0;
-    for (int s = 1; s <= 64; ++s) {
-        if (kt % s != 0) continue;
-        const int nk = kt / s;
-        if (nk % 2 != 0 || nk < 8) continue;
-        const long units = tiles * s, rounds = (units + 255) / 256;
-        const double eff = (double)units / (double)(rounds * 256);
-        // measured (tools/gemm_lab_prod LAB_V4_AB=1, profiles/r03_gemm_lab_v4w_ab.txt): +8.5 % with 144 K steps per unit
-        // (W[3072, 768], W[768, 3072] at 9216 rows), -5 % with 36 (W[768, 768] needs 16 splits to fill the chip and
-        // every unit ends in a 147 KB burst of atomics that all 256 blocks issue at the same instant)
-        if (mode != 2 && (eff < 0.85 || nk < 96)) continue;
-        const double cost = (double)rounds * (nk + 8.0);      // ~8 K steps of epilogue (atomics) per unit
-        if (cost < best - 1e-9) { best = cost; best_s = s; }
+    int best_s = 0, best_c = -1;
+    for (int c = 0; c < 3; ++c) {
+        const int BM = cfgs[c].bm, BN = cfgs[c].bn;
+        if (p.M % BM != 0 || p.N % BN != 0 || p.cseg % BM != 0) continue;
+        const long tiles = (long)(p.M / BM) * (p.N / BN);
+        for (int s = 1; s <= 64; ++s) {
+            if (kt % s != 0) continue;
+            const int nk = kt / s;
+            if (nk % 2 != 0 || nk < 8) continue;
+            const long units = tiles * s, rounds = (units + 255) / 256;
+            const double eff = (double)units / (double)(rounds * 256);
+            // measured (tools/gemm_lab_prod LAB_V4_AB=1, profiles/r03_gemm_lab_v4w_ab.txt): +8.5 % with 144 K steps per unit
+            // (W[3072, 768], W[768, 3072] at 9216 rows), -5 % with 36 (W[768, 768] needs 16 splits to fill the chip and
+            // every unit ends in a 147 KB burst of stores that all 256 blocks issue at the same instant)
+            if (mode != 2 && (eff < 0.85 || nk < 64)) continue;
+            // ~8 K steps of epilogue per unit; cost in units of one 16 x 16 tile K step per CU
+            const double cost = (double)rounds * (nk + 8.0) * (BM / 16) * (BN / 16) / cfgs[c].eff;
+            if (cost < best - 1e-9) { best = cost; best_s = s; best_c = c; }
+        }
     }
-    if (best_s == 0) return false;
+    if (best_c < 0) return -1;
+    const int BM = cfgs[best_c].bm, BN = cfgs[best_c].bn;
+    const long tiles = (long)(p.M / BM) * (p.N / BN);
     p.tiles_n = p.N / BN;
     p.n_small = (int)tiles;
     p.n_big = (int)(tiles * best_s);
     p.ktiles_per_split = kt / best_s;
     p.epi = best_s > 1 ? EPI_ATOMIC : EPI_ACCUM;
-    return true;
+    return best_c;
 }
 
 // splits: 1 = no split-K; < 0 = split-K launch (wgrad), choose the count; legacy_splits = count for the round-1 kernel
@@ -553,11 +560,12 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
     // vec_v2: 16-byte loads legal for the second-generation kernel (it tolerates a row-contiguous A whose row count is
     // not a multiple of 4 when the leading dimension leaves room for the last float4); default = same as `vec`
     if (planes == 0 && plan_v2<A_KC, B_KC>(p, vec_v2 < 0 ? vec : vec_v2 != 0, splits, pl)) {
-        if (!A_KC && !B_KC && splits < 0 && plan_v4w(p)) {
+        const int c4w = (!A_KC && !B_KC && splits < 0) ? plan_v4w(p) : -1;
+        if (c4w >= 0) {
             const int s4 = p.n_big / p.n_small;
             const bool det = s4 > 1 && deterministic();
             if (det && !det_prepare(st, p, s4)) return VB_E_WORKSPACE;
-            if (int e = launch_gemm_v4_tn(st, p)) return e;
+            if (int e = launch_gemm_v4_tn(st, p, c4w)) return e;
             return det ? det_finish(st, p, s4) : 0;
         }
         // persistent 288-row tiles (gemm_v4.h) where they fill the chip in whole rounds

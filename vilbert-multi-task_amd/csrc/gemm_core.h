@@ -215,7 +215,7 @@ int launch_gemm_v2_tn(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, 
 int launch_gemm_v4_nt(hipStream_t st, const GemmP& p, int tn);
 int launch_gemm_v4_nn(hipStream_t st, const GemmP& p, int tn);
 // persistent weight-gradient kernel (gemm_v4w.h); the launch parameters are filled by plan_v4w (gemm.hip)
-int launch_gemm_v4_tn(hipStream_t st, const GemmP& p);
+int launch_gemm_v4_tn(hipStream_t st, const GemmP& p, int cfg);
 
 // bf16-planes kernels (gemm_planes.hip, one object per plane count): launch for operand layouts (a_kc, b_kc)
 int launch_gemm_planes3(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);

@@ -111,9 +111,10 @@ int launch_v4(hipStream_t st, GemmP p) {
 
 #if VB_V2_LAYOUT == 2
 // persistent weight-gradient kernel (gemm_v4w.h): 384 x 96 tiles x K splits as work units
-__global__ __launch_bounds__(V4_THREADS, 4) void gemm_v4w_kernel(const GemmP p) {
+template <int WM, int TM, int TN>
+__global__ __launch_bounds__((V4WCfg<WM, TM, TN>::THREADS), (WM == 6 ? 4 : 3)) void gemm_v4w_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_block_v4w<4, 3>(p, smem);
+    gemm_block_v4w<WM, TM, TN>(p, smem);
 }
 #endif
 
@@ -137,15 +138,21 @@ int dispatch(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles
 
 namespace vbgemm {
 #if VB_V2_LAYOUT == 2
-int launch_gemm_v4_tn(hipStream_t st, const GemmP& p) {
-    using Cfg = V4WCfg<4, 3>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4w_kernel),
+template <int WM, int TM, int TN>
+int launch_v4w(hipStream_t st, const GemmP& p) {
+    using Cfg = V4WCfg<WM, TM, TN>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4w_kernel<WM, TM, TN>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (attr != hipSuccess) return (int)attr;
     const int grid = p.n_big < 256 ? p.n_big : 256;
-    hipLaunchKernelGGL(gemm_v4w_kernel, dim3(grid), dim3(V4_THREADS), Cfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_v4w_kernel<WM, TM, TN>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st, p);
     VB_LAUNCH_CHECK();
     return 0;
+}
+
+// cfg: 0 = 384 x 96 (12 MFMA waves), 1 = 256 x 128, 2 = 256 x 96 (8 MFMA waves)
+int launch_gemm_v4_tn(hipStream_t st, const GemmP& p, int cfg) {
+    return cfg == 0 ? launch_v4w<6, 4, 3>(st, p) : cfg == 1 ? launch_v4w<4, 4, 4>(st, p) : launch_v4w<4, 4, 3>(st, p);
 }
 #endif
 #if VB_V2_LAYOUT == 0

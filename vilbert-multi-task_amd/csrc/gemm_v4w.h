@@ -16,9 +16,15 @@
 
 namespace vbgemm {
 
-template <int TM, int TN>
+constexpr int Cfg_threads_guard(int mfma_waves) { return 64 * mfma_waves; }
+
+// WM = wave rows of the MFMA-wave grid (always 2 wave columns): 6 -> 12 MFMA waves, 384-row tiles with TM = 4 (weights with
+// 768 / 2304 / 3072 rows); 4 -> 8 MFMA waves (two per SIMD, 170 registers), 256-row tiles (the 1024 / 4096-row weights of
+// the image stream, the connection layers and bert_large).
+template <int WM, int TM, int TN>
 struct V4WCfg {
-    static constexpr int BM = 16 * TM * V4_WM, BN = 16 * TN * V4_WN;
+    static constexpr int MFMA_WAVES = WM * V4_WN, THREADS = 64 * (MFMA_WAVES + 1);
+    static constexpr int BM = 16 * TM * WM, BN = 16 * TN * V4_WN;
     static constexpr int A_SZ = 16 * BM, B_SZ = 16 * BN;
     static constexpr int STAGE = A_SZ + B_SZ;
     static constexpr int LDS_BYTES = V4_STAGES * STAGE * 4;
@@ -26,12 +32,13 @@ struct V4WCfg {
     static_assert(A_SZ % 256 == 0 && B_SZ % 256 == 0, "whole DMA instructions");
     static_assert(2 * NI <= 63, "vmcnt is a 6-bit counter");
     static_assert(2 * LDS_BYTES > 160 * 1024 && LDS_BYTES <= 160 * 1024, "exactly one block per CU");
+    static_assert(BM <= Cfg_threads_guard(MFMA_WAVES), "the bias-gradient sums use one MFMA-wave thread per tile row");
 };
 
-template <int TM, int TN>
+template <int WM, int TM, int TN>
 __device__ __forceinline__ void v4w_loader(const GemmP& p, const unsigned lds0, const int lane, const int nk,
                                            const int units, const int rounds) {
-    using Cfg = V4WCfg<TM, TN>;
+    using Cfg = V4WCfg<WM, TM, TN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NA = Cfg::NA, NB = Cfg::NB, NI = Cfg::NI, S = V4_STAGES;
     unsigned oa[NA], ob[NB];          // per-lane byte offsets inside a K tile (constant for the whole launch)
 #pragma unroll
@@ -92,9 +99,9 @@ __device__ __forceinline__ void v4w_loader(const GemmP& p, const unsigned lds0, 
     }
 }
 
-template <int TM, int TN>
+template <int WM, int TM, int TN>
 __device__ __forceinline__ void gemm_block_v4w(const GemmP& p, float* __restrict__ smem) {
-    using Cfg = V4WCfg<TM, TN>;
+    using Cfg = V4WCfg<WM, TM, TN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, S = V4_STAGES;
     const int units = p.n_big, tiles = p.n_small;
     const int nk = p.ktiles_per_split;       // even, the same for every unit
@@ -103,9 +110,9 @@ __device__ __forceinline__ void gemm_block_v4w(const GemmP& p, float* __restrict
     while (rounds * grid < units && v4_tile_of(b, rounds, grid, units) >= 0) ++rounds;
     if (rounds == 0) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == V4_MFMA_WAVES) {
+    if (wave == Cfg::MFMA_WAVES) {
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-        v4w_loader<TM, TN>(p, __builtin_amdgcn_readfirstlane(lds0), threadIdx.x & 63, nk, units, rounds);
+        v4w_loader<WM, TM, TN>(p, __builtin_amdgcn_readfirstlane(lds0), threadIdx.x & 63, nk, units, rounds);
         return;
     }
     f32x4 acc[TM][TN], afr[2][TM], bfr[2][TN];
