@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 11
+#define VB_ABI_VERSION 12
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -256,6 +256,14 @@ int64_t vb_layernorm_bwd_workspace(int64_t rows, int32_t n_cols);
 int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
                      const float* mean, const float* rstd, const float* gamma, float* dx,
                      float* dgamma, float* dbeta, float* workspace);
+/* The same with the dropout mask of the layer IN FRONT of the LayerNorm fused in (round 3): y = LayerNorm(dropout(
+ * dense(h), p) + x) is the shape of every BertSelfOutput / BertOutput / BertBiOutput (vilbert.py:471-473, 514-516, 850-
+ * 855); its backward needs dx (for the skip connection) AND dropout-masked dx (for the dense layer's GEMMs). dx_dropped
+ * [rows, n_cols] receives keep(seed, row * n_cols + col) ? dx / (1 - p) : 0 - the mask function of vb_linear_fwd's
+ * dropout epilogue / vb_dropout - in the same pass. n_cols <= 4096. */
+int vb_layernorm_bwd_drop(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
+                          const float* mean, const float* rstd, const float* gamma, float* dx, float* dgamma,
+                          float* dbeta, float* workspace, float* dx_dropped, float dropout_p, uint64_t seed);
 
 /* ------------------------------------------------------------------------------------------
  * vb_text_embed_ln_fwd: LayerNorm(word[ids] + pos[arange + pos_offset] + type[segment_ids])

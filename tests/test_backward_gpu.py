@@ -365,3 +365,56 @@ def test_fixed_layers_run_without_grad_and_train_the_rest():
     # the text embeddings feed only the frozen prefix, so they receive no gradient through the encoder
     assert model.bert.embeddings.position_embeddings.weight.grad is None
     assert model.bert.v_embeddings.image_embeddings.weight.grad is not None
+
+
+def test_gradient_side_dropout_rides_on_the_layernorm_backward():
+    """Round 3: the dropout mask of the dense layer in front of a LayerNorm is applied by the LayerNorm backward kernel
+    itself (vb_layernorm_bwd_drop) and handed to the dense node through a tensor tag. With dropout ON: (a) the
+    stand-alone vb_dropout launches of backward all but disappear, (b) every gradient is BIT-identical to the path
+    without the hand-over (same mask function, same arithmetic)."""
+    import vilbert.autograd_ops as AO
+    from vilbert import _native
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    was_det = _native._DET["wanted"]
+    _native.set_deterministic(True)          # bit-identity needs the ordered split-K reduce
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    sd = synth.make_state_dict(cfg, "pretraining")
+    x = synth.make_inputs(cfg, 8, 20, 37, with_labels=True)
+    names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+             "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
+    args = [x[n].to(DEV) for n in names]
+    calls = {"n": 0}
+    real_dropout = AO.ops.dropout
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real_dropout(*a, **k)
+
+    def run(handover):
+        tag = AO._tag_drop
+        if not handover:
+            AO._tag_drop = lambda y, p, s: y
+        AO.ops.dropout = counting
+        try:
+            m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+            m.load_state_dict(sd)
+            m = m.to(DEV).train()
+            AO._seed_counter = __import__("itertools").count(1)      # the same dropout seeds in both runs
+            loss = sum(l.mean() for l in m(*args))
+            calls["n"] = 0
+            loss.backward()
+            torch.cuda.synchronize()
+            return calls["n"], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            AO._tag_drop = tag
+            AO.ops.dropout = real_dropout
+    try:
+        n_off, g_off = run(False)
+        n_on, g_on = run(True)
+    finally:
+        _native.set_deterministic(was_det)
+    assert n_off >= 12 and n_on <= n_off - 12, (n_off, n_on)
+    skip = ("word_embeddings", "position_embeddings", "token_type_embeddings")     # scatter with atomics
+    for n in g_off:
+        if not any(k in n for k in skip):
+            assert torch.equal(g_off[n], g_on[n]), n

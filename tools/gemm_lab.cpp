@@ -203,9 +203,10 @@ template <class F>
 static void v4_ab(const char* kind, double fl, F fn) {
     if (!getenv("LAB_V4_AB")) return;
     double best[2] = {1e30, 1e30};
+    const int mode_a = getenv("LAB_AB_MODE_A") ? atoi(getenv("LAB_AB_MODE_A")) : 0;
     for (int rep = 0; rep < 3; ++rep)
         for (int m = 0; m < 2; ++m) {
-            vb_set_gemm_v4(m ? 2 : 0);
+            vb_set_gemm_v4(m ? 2 : mode_a);
             best[m] = std::min(best[m], time_us(fn, 20));
         }
     vb_set_gemm_v4(1);

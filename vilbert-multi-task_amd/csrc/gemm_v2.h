@@ -103,6 +103,8 @@ __device__ __forceinline__ void epilogue_v2(const GemmP& p, float* __restrict__ 
                 for (int e = 0; e < 4; ++e) unsafeAtomicAdd(c + e, v[e]);
             } else if (MODE == EPI_ACCUM) {
                 *reinterpret_cast<f32x4*>(c) = *reinterpret_cast<const f32x4*>(c) + v;
+            } else if (p.flags & 64) {
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(c));   // lab: streaming stores of the C tile
             } else {
                 *reinterpret_cast<f32x4*>(c) = v;
             }

@@ -6,6 +6,7 @@
 // passes, so every element is read from HBM once and written once. Statistics are two-pass
 // (mean, then the mean of squared deviations) exactly as the reference computes them.
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
@@ -347,7 +348,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int n_col
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
-                                                            float* __restrict__ dx, float* __restrict__ ws) {
+                                                            float* __restrict__ dx, float* __restrict__ ws,
+                                                            float* __restrict__ dxd, float drop_p, float drop_scale,
+                                                            uint64_t seed_in, const uint64_t* __restrict__ epoch) {
+    // dxd (optional): dx with the dropout mask of the layer in FRONT of this LayerNorm applied - the gradient that layer's
+    // backward GEMMs consume - written in the same pass (saves the separate vb_dropout launch over dx)
+    const uint64_t seed = dxd != nullptr ? vb_seed_with_epoch(seed_in, epoch) : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long part = (long)blockIdx.x * 4 + wave;
     const long row_begin = part * LNB_ROWS_PER_WAVE;
@@ -384,8 +390,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long rows, int n_col
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (i * 64 + lane) * 4;
-            if (col < n_cols)
-                *reinterpret_cast<f32x4*>(dx + row * n_cols + col) = (g[i] - m1 - xh[i] * m2) * rs;
+            if (col < n_cols) {
+                const f32x4 d = (g[i] - m1 - xh[i] * m2) * rs;
+                *reinterpret_cast<f32x4*>(dx + row * n_cols + col) = d;
+                if (dxd != nullptr) {
+                    f32x4 dd;
+                    const uint64_t idx = (uint64_t)(row * n_cols + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dd[e] = vb_keep(seed, idx + e, drop_p) ? d[e] * drop_scale : 0.f;
+                    *reinterpret_cast<f32x4*>(dxd + row * n_cols + col) = dd;
+                }
+            }
         }
     }
     constexpr bool BLOCK_REDUCE = NV <= 4;
@@ -560,9 +575,10 @@ extern "C" int64_t vb_layernorm_bwd_workspace(int64_t rows, int32_t n_cols) {
     return parts_padded * 2 * n_cols;
 }
 
-extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
-                                const float* mean, const float* rstd, const float* gamma, float* dx,
-                                float* dgamma, float* dbeta, float* workspace) {
+namespace {
+int layernorm_bwd_impl(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x, const float* mean,
+                       const float* rstd, const float* gamma, float* dx, float* dgamma, float* dbeta, float* workspace,
+                       float* dxd, float drop_p, uint64_t seed) {
     if (dy == nullptr || x == nullptr || mean == nullptr || rstd == nullptr || gamma == nullptr || dx == nullptr ||
         dgamma == nullptr || dbeta == nullptr || workspace == nullptr || rows <= 0)
         return VB_E_BADARG;
@@ -573,20 +589,23 @@ extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, cons
     const long blocks = (rows + LNB_ROWS_PER_BLOCK - 1) / LNB_ROWS_PER_BLOCK;
     const int width = 2 * n_cols;
     long parts = nv_for(n_cols) <= 4 ? blocks : blocks * 4;  // one partial per block / per wave
+    const float dscale = dxd != nullptr ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const uint64_t* epoch = dxd != nullptr ? vb_seed_epoch() : nullptr;
     if (nv_for(n_cols) > 16) {
+        if (dxd != nullptr) return VB_E_RANGE;    // (the fused mask is not offered for rows wider than 4096)
         hipLaunchKernelGGL(layernorm_bwd_wide_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (long)rows, n_cols, dy,
                            x, mean, rstd, gamma, dx, workspace);
         parts = rows;
     } else {
         switch (nv_for(n_cols)) {
-            case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
-            case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
-            case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
-            case 4: hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+            case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace, dxd, drop_p, dscale, seed, epoch); break;
+            case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace, dxd, drop_p, dscale, seed, epoch); break;
+            case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace, dxd, drop_p, dscale, seed, epoch); break;
+            case 4: hipLaunchKernelGGL((layernorm_bwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace, dxd, drop_p, dscale, seed, epoch); break;
             case 5: case 6: case 7: case 8:
-                hipLaunchKernelGGL((layernorm_bwd_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+                hipLaunchKernelGGL((layernorm_bwd_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace, dxd, drop_p, dscale, seed, epoch); break;
             default:
-                hipLaunchKernelGGL((layernorm_bwd_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace); break;
+                hipLaunchKernelGGL((layernorm_bwd_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, (long)rows, n_cols, dy, x, mean, rstd, gamma, dx, workspace, dxd, drop_p, dscale, seed, epoch); break;
         }
     }
     VB_LAUNCH_CHECK();
@@ -594,6 +613,23 @@ extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, cons
                        workspace, dgamma, dbeta, n_cols);
     VB_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+extern "C" int vb_layernorm_bwd(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
+                                const float* mean, const float* rstd, const float* gamma, float* dx,
+                                float* dgamma, float* dbeta, float* workspace) {
+    return layernorm_bwd_impl(stream, rows, n_cols, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, nullptr, 0.f, 0);
+}
+
+extern "C" int vb_layernorm_bwd_drop(void* stream, int64_t rows, int32_t n_cols, const float* dy, const float* x,
+                                     const float* mean, const float* rstd, const float* gamma, float* dx,
+                                     float* dgamma, float* dbeta, float* workspace, float* dx_dropped, float dropout_p,
+                                     uint64_t seed) {
+    if (dx_dropped == nullptr || !(dropout_p > 0.f && dropout_p < 1.f)) return VB_E_BADARG;
+    if (!vb_aligned16(dx_dropped)) return VB_E_ALIGN;
+    return layernorm_bwd_impl(stream, rows, n_cols, dy, x, mean, rstd, gamma, dx, dgamma, dbeta, workspace, dx_dropped,
+                              dropout_p, seed);
 }
 
 extern "C" int vb_text_embed_bwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, int32_t vocab,

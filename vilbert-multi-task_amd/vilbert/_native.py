@@ -160,6 +160,7 @@ SIGNATURES = {
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
     "vb_layernorm_bwd_workspace": (ctypes.c_int64, [_I64, _I32]),
     "vb_layernorm_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vb_layernorm_bwd_drop": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _U64]),
     "vb_text_embed_ln_fwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _P,
                                              _F32, _P, _P, _P, _P]),
     "vb_text_embed_bwd": (ctypes.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -190,7 +191,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 11:
+        if handle.vb_abi_version() != 12:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") == "fp8":

@@ -141,7 +141,7 @@ class LinearFn(Function):
         ctx.act, ctx.nseg = act, nseg
         ctx.drop = (drop_p, seed)
         ctx.has_bias = [b is not None for b in biases]
-        return y
+        return _tag_drop(y, drop_p, seed) if residual is not None and act is None else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -155,7 +155,7 @@ class LinearFn(Function):
             dy = dy.contiguous()     # (a row-strided gradient of padded logits feeds the GEMMs in place)
         dres = dy if ctx.needs_input_grad[1] else None
         if ctx.drop[0] > 0.0:
-            dy = ops.dropout(dy, ctx.drop[0], ctx.drop[1])
+            dy = _dropped(dy, ctx.drop)
         dpre = ops.act_bwd(dy, pre, ctx.act) if ctx.act is not None else dy
         dx = None
         if ctx.needs_input_grad[0]:
@@ -185,7 +185,7 @@ class FFNFn(Function):
         ctx.save_for_backward(x, dact, h, w1, w2, *[b for b in (b1, b2) if b is not None])
         ctx.act, ctx.drop = act, (drop_p, seed)
         ctx.has_bias = (b1 is not None, b2 is not None)
-        return y
+        return _tag_drop(y, drop_p, seed)
 
     @staticmethod
     def backward(ctx, dy):
@@ -194,7 +194,7 @@ class FFNFn(Function):
         b1 = rest.pop(0) if ctx.has_bias[0] else None
         b2 = rest.pop(0) if ctx.has_bias[1] else None
         dy = dy.contiguous()
-        dyd = ops.dropout(dy, ctx.drop[0], ctx.drop[1]) if ctx.drop[0] > 0.0 else dy
+        dyd = _dropped(dy, ctx.drop) if ctx.drop[0] > 0.0 else dy
         inter, hidden = w1.shape[0], w1.shape[1]
         dpre = ops.linear_bwd_input(dyd, [w2], inter, mul=dact)
         dw2 = db2 = dw1 = db1 = dx = None
@@ -209,11 +209,36 @@ class FFNFn(Function):
         return dx, dw1, db1, dw2, db2, None, None
 
 
-def _ln_bwd(dy, x, mean, rstd, gamma, beta, need_g, need_b):
-    """LayerNorm backward with dgamma / dbeta written straight into their arena slices when those are fresh."""
+def _ln_bwd(dy, x, mean, rstd, gamma, beta, need_g, need_b, drop=None):
+    """LayerNorm backward with dgamma / dbeta written straight into their arena slices when those are fresh.
+    drop = (p, seed) of the dense layer in front: dx comes back tagged with its dropout-masked twin (see _DROP_HINT)."""
     c = _Claims([gamma, beta], [need_g, need_b])
-    dx, dgamma, dbeta = ops.layernorm_bwd(dy, x, mean, rstd, gamma, c.fresh_or_none(0), c.fresh_or_none(1))
+    res = ops.layernorm_bwd(dy, x, mean, rstd, gamma, c.fresh_or_none(0), c.fresh_or_none(1), drop=drop)
+    dx, dgamma, dbeta = res[:3]
+    if len(res) == 4:
+        dx._vb_dropped = (drop[0], drop[1], res[3])
     return dx, (c.finish_overwrite(0, dgamma) if need_g else None), (c.finish_overwrite(1, dbeta) if need_b else None)
+
+
+# Dropout-mask hand-over between two autograd nodes (round 3, -66 launches per step). Every BertSelfOutput / BertOutput /
+# BertBiOutput is y = LayerNorm(dropout(dense(h), p) + x): LinearFn / FFNFn produce the pre-LayerNorm sum, LayerNormFn
+# consumes it. In backward the LayerNorm node computes dx and the dense node needs dropout(dx) - the same elements, the
+# mask is a function of (seed, index). The forward of the dense node tags its output tensor with (p, seed)
+# (`_vb_drop`), LayerNormFn.forward copies the tag into its context, its backward lets the LayerNorm kernel write the
+# masked gradient next to dx and tags dx with it (`_vb_dropped`), the dense node's backward uses the twin when the tag
+# matches its own (p, seed). Pure optimisation: without a matching tag every node falls back to its own vb_dropout.
+def _tag_drop(y, drop_p, seed):
+    if drop_p > 0.0:
+        y._vb_drop = (drop_p, seed)
+    return y
+
+
+def _dropped(dy, drop):
+    """dropout(dy) for the dense node's backward: the twin the LayerNorm kernel already wrote, or a vb_dropout launch."""
+    tag = getattr(dy, "_vb_dropped", None)
+    if tag is not None and tag[0] == drop[0] and tag[1] == drop[1] and tag[2].shape == dy.shape:
+        return tag[2]
+    return ops.dropout(dy, drop[0], drop[1])
 
 
 class LayerNormFn(Function):
@@ -223,13 +248,19 @@ class LayerNormFn(Function):
     def forward(ctx, x, gamma, beta, eps):
         y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, None, want_stats=True)
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.drop_hint = getattr(x, "_vb_drop", None)      # x = dropout(dense(h)) + residual of the node in front
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
-        dx, dgamma, dbeta = _ln_bwd(dy, x, mean, rstd, gamma, beta, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        return dx.view(x.shape), dgamma, dbeta, None
+        dx, dgamma, dbeta = _ln_bwd(dy, x, mean, rstd, gamma, beta, ctx.needs_input_grad[1], ctx.needs_input_grad[2],
+                                    drop=ctx.drop_hint)
+        out = dx.view(x.shape)
+        tag = getattr(dx, "_vb_dropped", None)
+        if tag is not None:
+            out._vb_dropped = (tag[0], tag[1], tag[2].view(x.shape))
+        return out, dgamma, dbeta, None
 
 
 class DropoutFn(Function):

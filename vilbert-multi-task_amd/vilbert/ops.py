@@ -391,12 +391,25 @@ def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma=None, dbeta=None, drop=None):
     """Returns (dx, dgamma, dbeta); x is the normalised input (the sum when the forward had x2). dgamma / dbeta:
-    optional [cols] targets (OVERWRITTEN - the column reduction is a deterministic two-stage sum)."""
+    optional [cols] targets (OVERWRITTEN - the column reduction is a deterministic two-stage sum).
+    drop = (p, seed): also returns, as a 4th value, dx with that dropout mask applied (the mask of the dense layer in
+    front of the LayerNorm), produced in the same pass."""
     dy, x = _contig(dy), _contig(x)
     rows, cols = _rows(x)
     dx = torch.empty_like(x)
+    if drop is not None and drop[0] > 0.0 and cols <= 4096:
+        dgamma = dgamma if dgamma is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
+        dbeta = dbeta if dbeta is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
+        ws = torch.empty(N.lib().vb_layernorm_bwd_workspace(rows, cols), dtype=torch.float32, device=x.device)
+        dxd = torch.empty_like(x)
+        N.check(N.lib().vb_layernorm_bwd_drop(
+            N.stream_ptr(), rows, cols, N.dev_f32(dy, "layernorm grad_output"), N.dev_f32(x, "layernorm input"),
+            N.dev_f32(mean, "layernorm mean"), N.dev_f32(rstd, "layernorm rstd"), N.dev_f32(gamma, "layernorm weight"),
+            dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), dxd.data_ptr(), drop[0], drop[1]),
+            "vb_layernorm_bwd_drop")
+        return dx, dgamma, dbeta, dxd
     dgamma = dgamma if dgamma is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
     dbeta = dbeta if dbeta is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
     ws = torch.empty(N.lib().vb_layernorm_bwd_workspace(rows, cols), dtype=torch.float32, device=x.device)
