@@ -307,7 +307,7 @@ def main():
 
     def comm_model(step64_ms):
         """What the gradient exchange will cost at N = 8, from what CAN be measured on one GPU: the real bucket layout
-        (vilbert/distributed.py, default 256 MiB buckets over the gradient arena), the moment each bucket's all-reduce is
+        (vilbert/distributed.py, buckets of 64 MiB = the default since round 3 and of 256 MiB over the gradient arena), the moment each bucket's all-reduce is
         launched inside backward (HIP events, world-size-1 RCCL group) and therefore the window of backward work left to
         hide it, next to SURVEY.md section 8(e)'s xGMI cost model (7 links x ~153 GB/s per GPU: ring all-reduce
         2 (N-1)/N S / 153 GB/s, direct reduce-scatter + all-gather over all links 2 (S/N) / 153 GB/s). A MODEL, recorded
@@ -318,58 +318,64 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29547")
             dist.init_process_group(backend="nccl", device_id=device, rank=0, world_size=1)
-        net = DistributedDataParallel(build_model(cfg, "pretraining", device).train())
-        optim = AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.98))
         names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
                  "image_attention_mask", "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
         link = 153e9
         out = {"what": "model (not a measurement of N > 1): bucket sizes and launch times measured on one GPU, xGMI cost from "
-                       "SURVEY.md 8(e)", "buckets_default_mib": 256, "n_gpus_modelled": 8}
-        for pb in (64, 256):
-            xb = synthetic_batch(cfg, pb, N_TOK, N_REG + 1, 11, True)
-            inp = tuple(xb[n].to(device) for n in names)
+                       "SURVEY.md 8(e)", "n_gpus_modelled": 8}
+        for mib in (64, 256):        # 64 MiB = the wrapper's default since round 3, 256 MiB = rounds 1-2
+            net = DistributedDataParallel(build_model(cfg, "pretraining", device).train(), message_size=mib * (1 << 20) // 4)
+            optim = AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.98))
+            res = {"n_buckets": len(net._buckets)}
+            for pb in (64, 256):
+                xb = synthetic_batch(cfg, pb, N_TOK, N_REG + 1, 11, True)
+                inp = tuple(xb[n].to(device) for n in names)
 
-            def one(trace):
-                optim.zero_grad(set_to_none=True)
-                lm, img, nsp = net(*inp)
-                loss = lm.mean() + img.mean() + nsp.mean()
-                net.trace = [] if trace else None
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                loss.backward()
-                e1.record()
-                optim.step()
-                return e0, e1
-            for _ in range(3):
-                one(False)
-            e0, e1 = one(True)
-            torch.cuda.synchronize()
-            bwd_ms = e0.elapsed_time(e1)
-            rows, t_ring, t_direct = [], 0.0, 0.0
-            for idx, nbytes, ev in net.trace:
-                ready = e0.elapsed_time(ev)
-                ring = 2.0 * 7 / 8 * nbytes / link * 1e3
-                direct = 2.0 * (nbytes / 8) / link * 1e3
-                t_ring = max(t_ring, ready) + ring
-                t_direct = max(t_direct, ready) + direct
-                rows.append({"bucket": idx, "mbytes": round(nbytes / 1e6, 1), "launched_ms_into_backward": round(ready, 2),
-                             "backward_left_ms": round(bwd_ms - ready, 2), "ring_ms_n8": round(ring, 2),
-                             "direct_ms_n8": round(direct, 2)})
-            net.trace = None
-            out["per_gpu_batch_%d" % pb] = {
-                "backward_ms": round(bwd_ms, 2), "buckets": rows,
-                "exposed_ms_ring": round(max(0.0, t_ring - bwd_ms), 2), "exposed_ms_direct": round(max(0.0, t_direct - bwd_ms), 2)}
-        e = out["per_gpu_batch_64"]
-        out["predicted_global512_n8"] = {
-            "step_ms_one_gpu_b64": round(step64_ms, 2),
-            "samples_per_s_ring": round(512 / ((step64_ms + e["exposed_ms_ring"]) * 1e-3), 1),
-            "samples_per_s_direct": round(512 / ((step64_ms + e["exposed_ms_direct"]) * 1e-3), 1),
-            "note": "8 x 64 samples per step; the all-reduces run one after the other on RCCL's stream from the moment each "
-                    "bucket is launched, what is not finished when backward ends is exposed"}
-        net.arena.release()
-        del net, optim
-        torch.cuda.empty_cache()
+                def one(trace):
+                    optim.zero_grad(set_to_none=True)
+                    lm, img, nsp = net(*inp)
+                    loss = lm.mean() + img.mean() + nsp.mean()
+                    net.trace = [] if trace else None
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    loss.backward()
+                    e1.record()
+                    optim.step()
+                    return e0, e1
+                for _ in range(3):
+                    one(False)
+                e0, e1 = one(True)
+                torch.cuda.synchronize()
+                bwd_ms = e0.elapsed_time(e1)
+                rows, t_ring, t_direct = [], 0.0, 0.0
+                for idx, nbytes, ev in net.trace:
+                    ready = e0.elapsed_time(ev)
+                    ring = 2.0 * 7 / 8 * nbytes / link * 1e3
+                    direct = 2.0 * (nbytes / 8) / link * 1e3
+                    t_ring = max(t_ring, ready) + ring
+                    t_direct = max(t_direct, ready) + direct
+                    rows.append({"bucket": idx, "mbytes": round(nbytes / 1e6, 1), "launched_ms_into_backward": round(ready, 2),
+                                 "backward_left_ms": round(bwd_ms - ready, 2), "ring_ms_n8": round(ring, 2),
+                                 "direct_ms_n8": round(direct, 2)})
+                net.trace = None
+                res["per_gpu_batch_%d" % pb] = {
+                    "backward_ms": round(bwd_ms, 2), "exposed_ms_ring": round(max(0.0, t_ring - bwd_ms), 2),
+                    "exposed_ms_direct": round(max(0.0, t_direct - bwd_ms), 2),
+                    "buckets": rows if mib == 256 or pb == 64 else "(%d buckets, same layout as batch 64)" % len(rows)}
+            e = res["per_gpu_batch_64"]
+            res["predicted_global512_n8"] = {
+                "step_ms_one_gpu_b64": round(step64_ms, 2),
+                "samples_per_s_ring": round(512 / ((step64_ms + e["exposed_ms_ring"]) * 1e-3), 1),
+                "samples_per_s_direct": round(512 / ((step64_ms + e["exposed_ms_direct"]) * 1e-3), 1)}
+            out["buckets_%d_mib" % mib] = res
+            net.arena.release()
+            del net, optim
+            torch.cuda.empty_cache()
+        out["note"] = ("8 x 64 samples per step; the all-reduces run one after the other on RCCL's stream from the moment each "
+                       "bucket is launched, what is not finished when backward ends is exposed; ring = per-link bound "
+                       "2 (N-1)/N S / 153 GB/s, direct = reduce-scatter + all-gather over all 7 links 2 (S/N) / 153 GB/s")
         return out
+
 
     def large_legs():
         """BASELINE configs[3]: bert_large_6layer_6conect.json (24 text layers, H = 1024, I = 4096, 16 x 64 heads) - forward

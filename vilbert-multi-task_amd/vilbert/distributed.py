@@ -10,8 +10,11 @@ Design for MI355X (8 GPUs, 7 xGMI links per GPU, 288 GB HBM each):
     its bucket, ``param.grad`` is a view of it, the all-reduce runs in place and the optimizer reads the same memory:
     no pack copy before the collective, no copy back after it (gradients produced by foreign autograd nodes are
     copied in, the exception);
-  * a few LARGE buckets (default 256 MiB: a ~1 GB model is 4-5 collectives, big enough to sit on RCCL's bandwidth
-    plateau over xGMI, few enough that launch latency is noise), laid out in reverse parameter-registration order,
+  * LARGE buckets (default 64 MiB = 16 M fp32 elements: a ~1 GB model is 14 collectives, each big enough to sit on
+    RCCL's bandwidth plateau over xGMI, few enough that launch latency is noise; rounds 1-2 used 256 MiB, but then the
+    first all-reduce starts only after 55 % of backward and the last 190 MB bucket is fully exposed - bench.py's
+    comm_model, measured launch times + the xGMI cost model: 1.6 ms exposed instead of 3.4 ms at 64 samples per GPU),
+    laid out in reverse parameter-registration order,
     i.e. roughly the order backward produces gradients (text layer 11, image layer 5, connection 5, ... embeddings
     last); each bucket's all-reduce is issued asynchronously the moment its last expected gradient arrives, so the
     communication of bucket i overlaps the backward GEMMs of bucket i + 1;
@@ -53,7 +56,7 @@ class DistributedDataParallel(nn.Module):
     constructor subset. ``model.module`` is the wrapped network (the reference checks ``hasattr(model,
     "module")`` when saving, train_concap.py:662-664)."""
 
-    def __init__(self, module, delay_allreduce=False, message_size=64 * 1024 * 1024, process_group=None, **_unused):
+    def __init__(self, module, delay_allreduce=False, message_size=16 * 1024 * 1024, process_group=None, **_unused):
         super(DistributedDataParallel, self).__init__()
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed.init_process_group must be called first")
