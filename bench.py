@@ -506,8 +506,11 @@ def main():
                        "fp32 activations (straight-through); outside the 1e-4 parity bar (tests/test_fp8_gpu.py)"
         notes["fp8+bf16"] = "opt-in: fp8 forward linears (as 'fp8') + bf16-operand backward GEMMs (as 'bf16'), fp32 master " \
                             "weights, accumulation, LayerNorm, attention and optimizer - throughput data point, no " \
-                            "convergence claim"
-        for mode in ("bf16x6", "bf16", "fp8", "fp8+bf16"):
+                            "convergence claim; measured gradient error vs exact fp32: tests/test_gemm_modes_gpu.py"
+        # (the "fp8" training mode - fp8 forward + exact-fp32 backward - is no longer a leg: BENCH_r02 showed it at the
+        #  rate of bf16x6; `--gemm-mode fp8` still runs it. Gradient errors of the two reduced-precision modes below:
+        #  tests/test_gemm_modes_gpu.py::test_reduced_precision_training_modes_report_their_gradient_error)
+        for mode in ("bf16x6", "bf16", "fp8+bf16"):
             _native.set_gemm_mode(mode)
             for _ in range(2):
                 step()
