@@ -356,15 +356,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
 // ------------------------------------------------------------------------------------------------
 constexpr int LDS_MAX_ROWS = 48;
 
+// Two operand blocks at once, every global load of the thread issued before the first LDS store (as one loop per
+// block the compiler emitted load -> s_waitcnt vmcnt(0) -> ds_write per 16 bytes: 12 dependent trips to HBM per block
+// at head_dim 128 - profiles/r03_attn_bench.txt).
 template <int D>
-__device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ g, long ld, int n_rows) {
+__device__ __forceinline__ void stage_rows2(float* __restrict__ s0, const float* __restrict__ g0, long ld0,
+                                            float* __restrict__ s1, const float* __restrict__ g1, long ld1, int n_rows) {
     // [n_rows][D] global (row stride ld) -> [LDS_MAX_ROWS][D + 4] LDS, rows >= n_rows zero-filled
-    constexpr int V4 = D / 4;
-    for (int f = threadIdx.x; f < LDS_MAX_ROWS * V4; f += 256) {
+    constexpr int V4 = D / 4, IT = (LDS_MAX_ROWS * V4 + 255) / 256;
+    f32x4 r0[IT], r1[IT];
+    // (unconditional loads from a clamped row: a select on the loaded value would put a wait behind every load)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int f = threadIdx.x + 256 * i;
+        const int r = min(f / V4, n_rows - 1), c4 = f % V4;
+        r0[i] = *reinterpret_cast<const f32x4*>(g0 + (long)r * ld0 + c4 * 4);
+        r1[i] = *reinterpret_cast<const f32x4*>(g1 + (long)r * ld1 + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int f = threadIdx.x + 256 * i;
         const int r = f / V4, c4 = f % V4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < n_rows) v = *reinterpret_cast<const f32x4*>(g + (long)r * ld + c4 * 4);
-        *reinterpret_cast<f32x4*>(s + r * (D + 4) + c4 * 4) = v;
+        if (f < LDS_MAX_ROWS * V4) {
+            const bool real = r < n_rows;
+            *reinterpret_cast<f32x4*>(s0 + r * (D + 4) + c4 * 4) = real ? r0[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(s1 + r * (D + 4) + c4 * 4) = real ? r1[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -375,7 +392,7 @@ __device__ __forceinline__ void load_frag_lds(f32x4 (&f)[DS], const float* s) {
 }
 
 template <int D, bool BWD>
-__global__ __launch_bounds__(256) void attn_q_lds_kernel(const AttnP p_in) {
+__global__ __launch_bounds__(256, 3) void attn_q_lds_kernel(const AttnP p_in) {   // 3 blocks per CU fit the LDS at head_dim 128
     AttnP p = p_in;
     p.seed = vb_seed_with_epoch(p_in.seed, p_in.epoch);
     extern __shared__ __attribute__((aligned(16))) float smem_att[];
@@ -389,15 +406,22 @@ __global__ __launch_bounds__(256) void attn_q_lds_kernel(const AttnP p_in) {
     const int nkt = p.n_kt;
     const bool drop = p.drop_p > 0.f;
 
-    stage_rows<D>(sK, p.K + (long)b * p.n_k * p.ldk + h * D, p.ldk, p.n_k);
-    stage_rows<D>(sV, p.V + (long)b * p.n_k * p.ldv + h * D, p.ldv, p.n_k);
+    // the wave's first query fragment travels together with the K / V blocks (one trip to HBM instead of two)
+    f32x4 qf_first[DS];
+    load_frag<DS>(qf_first, p.Q + ((long)b * p.n_q + min(wave * 16 + c, p.n_q - 1)) * p.ldq + h * D + 4 * g);
+    stage_rows2<D>(sK, p.K + (long)b * p.n_k * p.ldk + h * D, p.ldk, sV, p.V + (long)b * p.n_k * p.ldv + h * D, p.ldv, p.n_k);
     __syncthreads();
     const float* mrow = p.mask != nullptr ? p.mask + (long)b * p.n_k : nullptr;
 
     for (int qt = wave; qt < p.n_qt; qt += 4) {
         const int q_row = min(qt * 16 + c, p.n_q - 1);
         f32x4 qf[DS];
-        load_frag<DS>(qf, p.Q + ((long)b * p.n_q + q_row) * p.ldq + h * D + 4 * g);
+        if (qt == wave) {
+#pragma unroll
+            for (int i = 0; i < DS; ++i) qf[i] = qf_first[i];
+        } else {
+            load_frag<DS>(qf, p.Q + ((long)b * p.n_q + q_row) * p.ldq + h * D + 4 * g);
+        }
         const long prow = (bh * p.n_q + q_row) * p.n_k;
 
         f32x4 st[NT];
@@ -546,8 +570,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
     const int c = lane & 15, g = lane >> 4;
     const bool drop = p.drop_p > 0.f;
 
-    stage_rows<D>(sQ, p.Q + (long)b * p.n_q * p.ldq + h * D, p.ldq, p.n_q);
-    stage_rows<D>(sO, p.dO + (long)b * p.n_q * p.lddo + h * D, p.lddo, p.n_q);
+    stage_rows2<D>(sQ, p.Q + (long)b * p.n_q * p.ldq + h * D, p.ldq, sO, p.dO + (long)b * p.n_q * p.lddo + h * D, p.lddo, p.n_q);
     __syncthreads();
     const float* lse = p.lse + bh * p.n_q;
     const float* dvec = p.dvec + bh * p.n_q;
@@ -655,20 +678,40 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
     const int nkt = p.n_kt;
     const bool drop = p.drop_p > 0.f;
 
-    {   // stage the four operand blocks (coalesced 16-byte loads, rows of D floats)
+    {   // stage the four operand blocks (coalesced 16-byte loads, rows of D floats). ALL loads of a thread are issued
+        // before the first LDS store: with runtime loop bounds the compiler kept one load -> wait -> store round per
+        // iteration, i.e. ~10 dependent trips to HBM per block with only 8 waves per CU to hide them (round 3).
         const float* gk = p.K + (long)b * p.n_k * p.ldk + h * D;
         const float* gv = p.V + (long)b * p.n_k * p.ldv + h * D;
         const float* gq = p.Q + (long)b * p.n_q * p.ldq + h * D;
         const float* go = p.dO + (long)b * p.n_q * p.lddo + h * D;
-        for (int f = threadIdx.x; f < p.n_k * V4; f += 256) {
+        constexpr int IT = (LDS_MAX_ROWS * V4 + 255) / 256;
+        f32x4 rk[IT], rv[IT], rq[IT], ro[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int f = threadIdx.x + 256 * i;
             const int r = f / V4, c4 = (f % V4) * 4;
-            *reinterpret_cast<f32x4*>(sK + r * LD + c4) = *reinterpret_cast<const f32x4*>(gk + (long)r * p.ldk + c4);
-            *reinterpret_cast<f32x4*>(sV + r * LD + c4) = *reinterpret_cast<const f32x4*>(gv + (long)r * p.ldv + c4);
+            if (r < p.n_k) {
+                rk[i] = *reinterpret_cast<const f32x4*>(gk + (long)r * p.ldk + c4);
+                rv[i] = *reinterpret_cast<const f32x4*>(gv + (long)r * p.ldv + c4);
+            }
+            if (r < p.n_q) {
+                rq[i] = *reinterpret_cast<const f32x4*>(gq + (long)r * p.ldq + c4);
+                ro[i] = *reinterpret_cast<const f32x4*>(go + (long)r * p.lddo + c4);
+            }
         }
-        for (int f = threadIdx.x; f < p.n_q * V4; f += 256) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int f = threadIdx.x + 256 * i;
             const int r = f / V4, c4 = (f % V4) * 4;
-            *reinterpret_cast<f32x4*>(sQ + r * LD + c4) = *reinterpret_cast<const f32x4*>(gq + (long)r * p.ldq + c4);
-            *reinterpret_cast<f32x4*>(sO + r * LD + c4) = *reinterpret_cast<const f32x4*>(go + (long)r * p.lddo + c4);
+            if (r < p.n_k) {
+                *reinterpret_cast<f32x4*>(sK + r * LD + c4) = rk[i];
+                *reinterpret_cast<f32x4*>(sV + r * LD + c4) = rv[i];
+            }
+            if (r < p.n_q) {
+                *reinterpret_cast<f32x4*>(sQ + r * LD + c4) = rq[i];
+                *reinterpret_cast<f32x4*>(sO + r * LD + c4) = ro[i];
+            }
         }
     }
     __syncthreads();

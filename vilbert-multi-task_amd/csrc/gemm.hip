@@ -483,6 +483,105 @@ int det_finish(hipStream_t st, const GemmP& p, int splits) {
     return 0;
 }
 
+// ---- skinny weight gradient: dW[seg_n, K] += dY^T X for K <= 8 input features (the 5-wide region-location projection
+// of the image embeddings, reference vilbert.py:385-386). As a GEMM this is a 1024 x 5 output reduced over ~9.5 k rows:
+// the tiled kernels waste 27 of 32 columns and, without atomics, cannot split the reduction (482 us per step in
+// profiles/r03_bench_train_b256_gemm_breakdown.txt). Here it is what it is - one streaming pass over dY: a block owns
+// 256 columns x one slab of rows, a wave every fourth row of the slab (the X row is wave-uniform: scalar loads), a lane 4
+// columns; the four waves are summed through LDS and the slabs through the deterministic workspace in slab order
+// (or with fp32 atomics when no workspace is registered). Bias gradient = the same sum with x = 1.
+constexpr int SK_KMAX = 8, SK_SLABS = 128;
+
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(int M, int seg_n, int K, const float* __restrict__ dY, long ldy,
+                                                           const float* __restrict__ X, long ldx, float* __restrict__ dW,
+                                                           long ldw, float* __restrict__ dbias, float* __restrict__ ws,
+                                                           int rows_per_slab) {
+    __shared__ float red[3][64][4 * (SK_KMAX + 1)];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 256 + 4 * lane;
+    const bool live = n0 < seg_n;                      // (seg_n % 4 == 0: a lane's 4 columns are all in or all out)
+    const int slab = blockIdx.y;
+    const int r0 = slab * rows_per_slab, r1 = min(M, r0 + rows_per_slab);
+    f32x4 acc[SK_KMAX + 1];
+#pragma unroll
+    for (int k = 0; k <= SK_KMAX; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const f32x4 dy = live ? *reinterpret_cast<const f32x4*>(dY + (long)r * ldy + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ xr = X + (long)r * ldx;
+#pragma unroll
+        for (int k = 0; k < SK_KMAX; ++k)
+            if (k < K) acc[k] += dy * xr[k];
+        acc[SK_KMAX] += dy;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k <= SK_KMAX; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave - 1][lane][4 * k + e] = acc[k][e];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
+#pragma unroll
+    for (int k = 0; k <= SK_KMAX; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k][e] += (red[0][lane][4 * k + e] + red[1][lane][4 * k + e]) + red[2][lane][4 * k + e];
+    if (ws != nullptr) {
+        // partials [slab][j = 0 .. K][seg_n], j = K: bias
+        float* __restrict__ w = ws + (long)slab * (K + 1) * seg_n + n0;
+#pragma unroll
+        for (int k = 0; k < SK_KMAX; ++k)
+            if (k < K) *reinterpret_cast<f32x4*>(w + (long)k * seg_n) = acc[k];
+        *reinterpret_cast<f32x4*>(w + (long)K * seg_n) = acc[SK_KMAX];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < SK_KMAX; ++k)
+                if (k < K) atomicAdd(dW + (long)(n0 + e) * ldw + k, acc[k][e]);
+            if (dbias != nullptr) atomicAdd(dbias + n0 + e, acc[SK_KMAX][e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_skinny_reduce_kernel(int slabs, int seg_n, int K, const float* __restrict__ ws,
+                                                                  float* __restrict__ dW, long ldw, float* __restrict__ dbias) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)(K + 1) * seg_n) return;
+    const int j = (int)(i / seg_n), n = (int)(i % seg_n);
+    float acc = 0.f;
+    for (int sl = 0; sl < slabs; ++sl) acc += ws[((long)sl * (K + 1) + j) * seg_n + n];
+    if (j < K) dW[(long)n * ldw + j] += acc;
+    else if (dbias != nullptr) dbias[n] += acc;
+}
+
+// -> 0 launched, > 0 error, -1 not eligible (the caller takes the GEMM path)
+int launch_wgrad_skinny(hipStream_t st, const vb_linear_bwd_weight_args* a) {
+    if (a->nseg != 1 || a->K > SK_KMAX || a->M < 256 || a->seg_n % 4 != 0 || a->ldy % 4 != 0 || !vb_aligned16(a->dY)) return -1;
+    if (gemm_mode() != 0) return -1;      // (the reduced-precision modes keep their own arithmetic)
+    float* ws = nullptr;
+    const int slabs = SK_SLABS;
+    if (deterministic()) {
+        const size_t need = (size_t)slabs * (a->K + 1) * a->seg_n * sizeof(float);
+        const size_t slice = g_det_bytes / DET_SLICES / 16 * 16;
+        const int k = det_slice_of(st);
+        if (k < 0 || need > slice) return VB_E_WORKSPACE;
+        ws = g_det_ws + (size_t)k * (slice / sizeof(float));
+    }
+    const int rows_per_slab = (int)((a->M + slabs - 1) / slabs);
+    hipLaunchKernelGGL(wgrad_skinny_kernel, dim3((unsigned)((a->seg_n + 255) / 256), (unsigned)slabs), dim3(256), 0, st, (int)a->M,
+                       (int)a->seg_n, (int)a->K, a->dY, (long)a->ldy, a->X, (long)a->ldx, a->dW[0], (long)a->ldw, a->dbias[0], ws,
+                       rows_per_slab);
+    VB_LAUNCH_CHECK();
+    if (ws != nullptr) {
+        const long work = (long)(a->K + 1) * a->seg_n;
+        hipLaunchKernelGGL(wgrad_skinny_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, slabs, (int)a->seg_n,
+                           (int)a->K, ws, a->dW[0], (long)a->ldw, a->dbias[0]);
+        VB_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int plan_v4(const GemmP& p, bool b_kc) {
     const int mode = gemm_v4_mode();
     if (mode == 0) return 0;
@@ -795,6 +894,10 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
                 if (e != hipSuccess) return (int)e;
             }
         }
+    }
+    {
+        const int e = launch_wgrad_skinny(st, a);      // in_features <= 8: one streaming pass instead of a 5-column GEMM
+        if (e >= 0) return e;
     }
     bool same_bias = true;  // the fused launch needs bias gradients for all segments or for none
     for (int s = 1; s < a->nseg; ++s) same_bias = same_bias && ((a->dbias[s] != nullptr) == (a->dbias[0] != nullptr));

@@ -283,8 +283,28 @@ def check(code, what):
         raise RuntimeError("%s failed: [%d] %s" % (what, code, msg.decode() if msg else "?"))
 
 
+# torch.cuda.current_stream() builds a Stream object through several layers of Python (~3.5 us, and an eager step at
+# 64 samples asks for the stream ~1,400 times: tools/host_profile.py); these two go straight to the C++ getters.
+_cuda_raw_stream = torch._C._cuda_getCurrentRawStream
+_cuda_device = torch._C._cuda_getDevice
+
+
+def current_device():
+    return _cuda_device()
+
+
+def raw_stream(device_index=None):
+    """hipStream_t (as an int) torch currently launches on, for `device_index` (default: the current device)."""
+    return _cuda_raw_stream(_cuda_device() if device_index is None else device_index)
+
+
+def set_stream(st):
+    """Make the torch.cuda.Stream `st` current (torch.cuda.set_stream without its Python layers)."""
+    torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_cuda_raw_stream(_cuda_device()))
 
 
 def dev_f32(t, what):

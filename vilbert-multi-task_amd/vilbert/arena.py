@@ -26,6 +26,8 @@ import weakref
 
 import torch
 
+from . import _native as _N
+
 # param.data_ptr() -> (weak reference to the arena, index). Weak: an arena lives exactly as long as its owner (the
 # optimizer / data-parallel wrapper that built it) or a gradient view of it does; a long-lived process that builds many
 # models (test suites, bench legs, sweeps) must not keep every model-sized gradient buffer alive through this table.
@@ -72,6 +74,8 @@ class GradArena(object):
         self._clean = True             # flat is all zeros
         self._zero_stream = None
         self._zero_event = None
+        self._fill_seen = set()        # raw streams already ordered behind this pass's zero fill
+        self._dev_index = dev.index if self._cuda else None
         self._listeners = []           # objects with .arena_written(index) / .arena_backward_done()
         self._taken_over = 0
         me = weakref.ref(self)
@@ -123,9 +127,10 @@ class GradArena(object):
     def wait_for_fill(self):
         """Writers on another stream than the one that zero-filled the arena must wait for the fill."""
         if self._cuda and self._zero_event is not None:
-            cur = torch.cuda.current_stream(self.flat.device)
-            if cur != self._zero_stream:
-                cur.wait_event(self._zero_event)
+            raw = _N.raw_stream(self._dev_index)
+            if raw not in self._fill_seen:      # (a stream that waited once is ordered behind the fill for good)
+                self._fill_seen.add(raw)
+                torch.cuda.current_stream(self.flat.device).wait_event(self._zero_event)
 
     def note_foreign_write(self, index):
         """The caller is about to write slice `index` itself during a backward pass (see enter_pass)."""
@@ -139,6 +144,7 @@ class GradArena(object):
         accumulating = any(self.owns(p, i) for i, p in enumerate(self.params))
         # an event of an earlier pass (possibly recorded inside a graph capture) must never order this pass
         self._zero_event, self._zero_stream = None, None
+        self._fill_seen = set()
         if not accumulating:
             if not self._clean:
                 self.flat.zero_()
@@ -146,6 +152,7 @@ class GradArena(object):
                 self._zero_stream = torch.cuda.current_stream(self.flat.device)
                 self._zero_event = torch.cuda.Event()
                 self._zero_event.record(self._zero_stream)
+                self._fill_seen.add(self._zero_stream.cuda_stream)
         self._clean = False
         self._accumulating = accumulating
         torch.autograd.Variable._execution_engine.queue_callback(self._end_pass)
@@ -163,7 +170,9 @@ class GradArena(object):
         e = lookup(param)
         if e is None or e[0] is not self:
             return None, None
-        i = e[1]
+        return self._claim_at(param, e[1])
+
+    def _claim_at(self, param, i):
         if not self.enter_pass():
             return None, None                      # not inside a backward pass (manual call of a backward op)
         self.wait_for_fill()
@@ -182,8 +191,7 @@ class GradArena(object):
 
     def alias(self, index):
         """A fresh tensor object over the slice (autograd steals it: use_count 1, no copy)."""
-        o, sh = self.offsets[index], self.shapes[index]
-        return self.flat[o:o + sh.numel()].view(sh)
+        return self.views[index].detach()
 
 
 # callables run at the end of every backward pass that wrote into an arena (engine callback, on the thread and stream that
@@ -196,7 +204,7 @@ def claim(param):
     e = lookup(param)
     if e is None:
         return None, None, None, None
-    view, mode = e[0].claim(param)
+    view, mode = e[0]._claim_at(param, e[1])
     if view is None:
         return None, None, None, None
     return view, mode, e[0], e[1]

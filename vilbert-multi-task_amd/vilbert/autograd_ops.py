@@ -11,6 +11,7 @@ import itertools
 import torch
 from torch.autograd import Function
 
+from . import _native as N
 from . import arena as _arena
 from . import ops
 
@@ -47,25 +48,31 @@ def set_wgrad_stream(on):
     return prev
 
 
-def _wgrad_stream(cur):
-    key = (cur.device.index, cur.cuda_stream)
-    st = _WGRAD["streams"].get(key)
-    if st is None:
-        st = _WGRAD["streams"][key] = torch.cuda.Stream(device=cur.device)
-    return st
+def _wgrad_stream(device, raw):
+    """(side stream, torch.cuda.Stream object of the raw stream `raw`) for weight gradients of work launched on `raw`.
+    Keyed on the raw handle so that the hot path never builds Stream objects (tools/host_profile.py); `raw` must be
+    the stream that is current on `device` when this is called."""
+    key = (device.index, raw)
+    ent = _WGRAD["streams"].get(key)
+    if ent is None:
+        ent = _WGRAD["streams"][key] = (torch.cuda.Stream(device=device), torch.cuda.current_stream(device))
+    return ent
 
 
 def join_wgrad_streams(into=None, clear=False):
     """Make `into` (default: the current stream) wait for every weight-gradient side stream of ITS device with work in
     flight (the bookkeeping is per device: backward threads of different devices never touch each other's entry)."""
-    if _WGRAD["used"]:
-        cur = into if into is not None else torch.cuda.current_stream()
-        mine = _WGRAD["used"].get(cur.device.index)
-        if mine:
-            for st in list(mine.values()):
-                cur.wait_stream(st)
-            if clear:
-                mine.clear()
+    used = _WGRAD["used"]
+    if not used:
+        return
+    mine = used.get(into.device.index if into is not None else N.current_device())
+    if not mine:
+        return
+    cur = into if into is not None else torch.cuda.current_stream()
+    for st in list(mine.values()):
+        cur.wait_stream(st)
+    if clear:
+        mine.clear()
 
 
 _arena.END_PASS_HOOKS.append(lambda: join_wgrad_streams(clear=True))
@@ -111,14 +118,16 @@ def _wgrad(dy, x, weights, biases_present, need_w, need_b):
     wanted = [c for c, n in zip(cw.c, need_w) if n] + [c for c, n in zip(cb.c, need_b) if n]
     side = _WGRAD["on"] and dy.is_cuda and len(wanted) > 0 and all(c[1] == "fresh" for c in wanted)
     if side:
-        cur = torch.cuda.current_stream(dy.device)
-        ws = _wgrad_stream(cur)
+        ws, cur = _wgrad_stream(dy.device, N.raw_stream(dy.device.index))
         ws.wait_stream(cur)
-        with torch.cuda.stream(ws):
+        N.set_stream(ws)
+        try:
             dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
+        finally:
+            N.set_stream(cur)
         dy.record_stream(ws)
         x.record_stream(ws)
-        _WGRAD["used"].setdefault(cur.device.index, {})[ws.cuda_stream] = ws
+        _WGRAD["used"].setdefault(dy.device.index, {})[ws.cuda_stream] = ws
     else:
         dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
     return ([cw.out(s, dws[s]) if need_w[s] else None for s in range(nseg)],
