@@ -440,7 +440,7 @@ int det_slice_of(hipStream_t st) {
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ cs_ws,
-                                                            int splits, long stride, int M, int N, GemmP p) {
+                                                            int splits, int cs_slices, long stride, int M, int N, GemmP p) {
     // C[r][c] += sum over the splits (in order) of ws[s][r][c]; bias gradient: colsum[r] += sum of cs_ws[s][r]
     const long n4 = (long)M * (N / 4);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     } else if (cs_ws != nullptr && i - n4 < M) {
         const int r = (int)(i - n4);
         float acc = cs_ws[r];
-        for (int s = 1; s < splits; ++s) acc += cs_ws[(long)s * M + r];
+        for (int s = 1; s < cs_slices; ++s) acc += cs_ws[(long)s * M + r];
         const int sg = r / p.cseg;
         p.colsum[sg][r - sg * p.cseg] += acc;
     }
@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Points the launch at the workspace (-> the kernels store partials instead of adding atomically). false = the
 // registered workspace is too small for `splits` partial copies of C.
 bool det_prepare(hipStream_t st, GemmP& p, int splits) {
-    const size_t need = ((size_t)splits * p.M * p.N + (size_t)splits * p.M) * sizeof(float);
+    if (p.det_cs_parts < 1) p.det_cs_parts = 1;
+    const size_t need = ((size_t)splits * p.M * p.N + (size_t)splits * p.det_cs_parts * p.M) * sizeof(float);
     const size_t slice = g_det_bytes / DET_SLICES / 16 * 16;
     const int k = det_slice_of(st);
     if (k < 0 || need > slice) return false;
@@ -478,7 +479,7 @@ int det_finish(hipStream_t st, const GemmP& p, int splits) {
     const bool cs = p.colsum[0] != nullptr;
     const long work = (long)p.M * (p.N / 4) + (cs ? p.M : 0);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p.det_ws, cs ? p.det_cs : nullptr,
-                       splits, p.det_stride, p.M, p.N, p);
+                       splits, splits * p.det_cs_parts, p.det_stride, p.M, p.N, p);
     VB_LAUNCH_CHECK();
     return 0;
 }
@@ -558,7 +559,6 @@ __global__ __launch_bounds__(256) void wgrad_skinny_reduce_kernel(int slabs, int
 // -> 0 launched, > 0 error, -1 not eligible (the caller takes the GEMM path)
 int launch_wgrad_skinny(hipStream_t st, const vb_linear_bwd_weight_args* a) {
     if (a->nseg != 1 || a->K > SK_KMAX || a->M < 256 || a->seg_n % 4 != 0 || a->ldy % 4 != 0 || !vb_aligned16(a->dY)) return -1;
-    if (gemm_mode() != 0) return -1;      // (the reduced-precision modes keep their own arithmetic)
     float* ws = nullptr;
     const int slabs = SK_SLABS;
     if (deterministic()) {
@@ -702,11 +702,19 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         p.mul = nullptr;
         if (p.epi == EPI_MUL) p.epi = EPI_STORE;
     }
+    bool det_legacy = false;
     if (splits < 0) {
-        splits = deterministic() ? 1 : legacy_splits;    // (the round-1 kernel only splits with atomics)
+        // weight gradient on the round-1 / bf16-planes kernels: split-K with fp32 atomics, or - deterministic mode -
+        // through the workspace (N % 4 == 0: the reduce kernel works in float4; no room in the slice: unsplit)
+        splits = legacy_splits;
         const int kt_total = (p.K + BK - 1) / BK;
         p.ktiles_per_split = (kt_total + splits - 1) / splits;
         splits = (kt_total + p.ktiles_per_split - 1) / p.ktiles_per_split;
+        if (deterministic() && splits > 1) {
+            p.det_cs_parts = planes != 0 ? 2 : 1;
+            det_legacy = p.N % 4 == 0 && det_prepare(st, p, splits);
+            if (!det_legacy) { splits = 1; p.ktiles_per_split = kt_total; }
+        }
         p.epi = splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
     }
     plan_tiles(p, splits, planes != 0);
@@ -722,6 +730,7 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, block, GEMM_LDS_BYTES, st, p);
     }
     VB_LAUNCH_CHECK();
+    if (det_legacy) return det_finish(st, p, splits);
     if (want_d != nullptr)
         if (int e = launch_act_grad_inplace(st, p.M, p.N, want_d, p.ldp, p.act)) return e;
     if (want_mul != nullptr)

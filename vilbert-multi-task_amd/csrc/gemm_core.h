@@ -44,6 +44,7 @@ struct GemmP {
     // plain [M, N] matrix (and its bias-gradient partial to det_cs + s * M) instead of adding into C with atomics; a
     // second kernel sums the partials in split order (splitk_reduce_kernel)
     float* det_ws; float* det_cs; long det_stride;
+    int det_cs_parts;          // bias-gradient partials per (split, row): 1, or 2 for the bf16-plane kernels (two threads per row)
 };
 
 // XCD-aware bijective remap of a linear block id over `nb` blocks (guide T1).
@@ -90,7 +91,8 @@ __device__ __forceinline__ void epilogue_full(const GemmP& p, float* __restrict_
 // pre-activation store, plain / accumulating / atomic stores.
 template <int TM, int TN, bool A_KC, bool B_KC>
 __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc)[TM][TN], const int m0, const int n0,
-                                              const bool want_colsum, const float csum, const int crow) {
+                                              const bool want_colsum, const float csum, const int crow,
+                                              const int cpart = 0) {
     constexpr int RA = 64 * TM, RB = 64 * TN;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -100,6 +102,28 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, const f32x16 (&acc
     const int cs = m0 / p.cseg;
     const int mloc = m0 - cs * p.cseg;  // row of the tile inside its segment
     // crow = the tile row whose (partial) sum over this block's K range the thread holds
+    if (p.det_ws != nullptr) {
+        // deterministic split-K (weight gradients): this split's partial tile goes to its workspace slice as a plain
+        // [M, N] matrix, its bias-gradient partial to det_cs; splitk_reduce_kernel adds the slices in split order
+        if (want_colsum && mloc + crow < p.cseg && m0 + crow < p.M)
+            p.det_cs[((long)blockIdx.y * p.det_cs_parts + cpart) * p.M + m0 + crow] = csum;
+        float* __restrict__ w = p.det_ws + (long)blockIdx.y * p.det_stride;
+        const int r0d = m0 + wm * 32 * TM + 4 * hi, c0d = n0 + wn * 32 * TN + l31;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = c0d + j * 32;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0d + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) w[(long)row * p.N + col] = acc[i][j][r];
+                }
+            }
+        }
+        return;
+    }
     if (want_colsum && mloc + crow < p.cseg && m0 + crow < p.M) unsafeAtomicAdd(p.colsum[cs] + mloc + crow, csum);
 
     // Epilogue. Accumulator map (32x32): col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).

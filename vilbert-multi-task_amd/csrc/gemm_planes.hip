@@ -300,7 +300,7 @@ __device__ __forceinline__ void gemm_tile_planes(const GemmP& p, char* __restric
         else kstep(kt, ra2, rb2, ra, rb, ld, stq);
     }
 
-    tile_epilogue<TM, TN, A_KC, B_KC>(p, acc, m0, n0, want_colsum, csum, ua_row);
+    tile_epilogue<TM, TN, A_KC, B_KC>(p, acc, m0, n0, want_colsum, csum, ua_row, ua_half);   // two threads hold a row's sum
 }
 
 template <bool A_KC, bool B_KC, bool VEC, int NPL>
