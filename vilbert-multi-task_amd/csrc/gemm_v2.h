@@ -57,11 +57,60 @@ __device__ __forceinline__ int v2_swz(int row) { return (-(row >> 2)) & 3; }
 // Epilogue of the transposed accumulator map: lane (l15 = lane & 15, g = lane >> 4), register r of tile (i, j)
 // holds C[row = tile_m + l15][col = tile_n + 4 g + r]. MODE as in gemm_core.h plus EPI_MUL (c = v * R: the
 // saved activation derivative applied to the incoming gradient).
-template <int MODE, int TM, int TN, bool BIAS_SEG>
+template <int MODE, int TM, int TN, bool BIAS_SEG, int EXT_DEPTH = 2>
 __device__ __forceinline__ void epilogue_v2(const GemmP& p, float* __restrict__ cbase, const f32x4 (&acc)[TM][TN],
                                             int row0, int col0, bool lead, bool full) {
     // row0 / col0: this lane's first row / column (global indices); cbase + row * ldc addresses global row `row`
     const uint64_t seed = MODE == EPI_RES_DROP ? vb_seed_with_epoch(p.seed, p.epoch) : 0;
+    constexpr bool EXT = EXT_DEPTH > 0 && (MODE == EPI_RES || MODE == EPI_RES_DROP || MODE == EPI_MUL || MODE == EPI_ACCUM);
+    if (EXT && full) {
+        // Interior tile of an epilogue that READS a second [M, N] operand (residual, activation derivative, C itself):
+        // all of the wave tile's loads are issued before the first store. The generic loop below interleaves
+        // load -> use -> store per fragment behind per-fragment bounds branches, i.e. TM x TN dependent trips to memory
+        // per tile (round 3: the image stream's dgrads, which all carry such an operand, ran at 99 TF against 113 TF for
+        // its forward launches - profiles/r03_bench_train_b256_gemm_breakdown.txt).
+        const float* ebase = MODE == EPI_MUL ? p.mul : (MODE == EPI_ACCUM ? cbase : p.R);
+        const long eld = MODE == EPI_MUL ? p.ldmul : (MODE == EPI_ACCUM ? (long)p.ldc : (long)p.ldr);
+        const bool use = MODE == EPI_MUL || MODE == EPI_ACCUM || lead;
+        // rolling by output column block (EXT_DEPTH 2): the TM loads of block j + 1 are in flight while block j is finished
+        // and stored; EXT_DEPTH 1 (the persistent kernels, which run at a hard 128-register budget): the TM loads of a
+        // block together, then its stores
+        f32x4 ext[EXT_DEPTH > 0 ? EXT_DEPTH : 1][TM];
+        auto fetch = [&](int j, f32x4 (&dst)[TM]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                dst[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (use) dst[i] = *reinterpret_cast<const f32x4*>(ebase + (long)(row0 + i * 16) * eld + col0 + j * 16);
+            }
+        };
+        if (EXT_DEPTH == 2) fetch(0, ext[0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (EXT_DEPTH == 1) fetch(j, ext[0]);
+            else if (j + 1 < TN) fetch(j + 1, ext[(j + 1) & (EXT_DEPTH > 1 ? 1 : 0)]);
+            const int col = col0 + j * 16;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (lead) {
+                const int sg = BIAS_SEG ? col / p.bseg : 0;
+                const float* bp = p.bias[sg];
+                if (bp != nullptr) bv = *reinterpret_cast<const f32x4*>(bp + (col - (BIAS_SEG ? sg * p.bseg : 0)));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = row0 + i * 16;
+                f32x4 v = acc[i][j] + bv;
+                if (MODE == EPI_RES_DROP) {
+                    const uint64_t idx = (uint64_t)((long)row * p.N + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = vb_keep(seed, idx + e, p.drop_p) ? v[e] * p.drop_scale : 0.f;
+                }
+                if (MODE == EPI_MUL) v *= ext[j & (EXT_DEPTH > 1 ? 1 : 0)][i];
+                else v += ext[j & (EXT_DEPTH > 1 ? 1 : 0)][i];
+                *reinterpret_cast<f32x4*>(cbase + (long)row * p.ldc + col) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + j * 16;

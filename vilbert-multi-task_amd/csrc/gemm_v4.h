@@ -337,13 +337,16 @@ __device__ __forceinline__ void gemm_block_v4(const GemmP& p, float* __restrict_
         float* cbase = p.C[0];
         const int row0 = m0 + wm * 16 * TM + l15, col0 = n0 + wn * 16 * TN + 4 * g;
         constexpr bool FWD = B_KC, DGRAD = !B_KC;
-        if (FWD && p.epi == EPI_GELU) epilogue_v2<EPI_GELU, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
-        else if (FWD && p.epi == EPI_DGELU) epilogue_v2<EPI_DGELU, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
-        else if (FWD && p.epi == EPI_RES_DROP) epilogue_v2<EPI_RES_DROP, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
-        else if (p.epi == EPI_RES) epilogue_v2<EPI_RES, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
-        else if (DGRAD && p.epi == EPI_MUL) epilogue_v2<EPI_MUL, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
-        else if (DGRAD && p.epi == EPI_ACCUM) epilogue_v2<EPI_ACCUM, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
-        else epilogue_v2<EPI_STORE, TM, TN, FWD>(p, cbase, acc, row0, col0, true, full);
+        // batched loads of an epilogue's second operand (gemm_v2.h): dgrad only - the forward variants (+ bias, + mask hash)
+        // spill at this kernel's 128 registers with them
+        constexpr int XD = FWD ? 0 : 1;
+        if (FWD && p.epi == EPI_GELU) epilogue_v2<EPI_GELU, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
+        else if (FWD && p.epi == EPI_DGELU) epilogue_v2<EPI_DGELU, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
+        else if (FWD && p.epi == EPI_RES_DROP) epilogue_v2<EPI_RES_DROP, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
+        else if (p.epi == EPI_RES) epilogue_v2<EPI_RES, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
+        else if (DGRAD && p.epi == EPI_MUL) epilogue_v2<EPI_MUL, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
+        else if (DGRAD && p.epi == EPI_ACCUM) epilogue_v2<EPI_ACCUM, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
+        else epilogue_v2<EPI_STORE, TM, TN, FWD, XD>(p, cbase, acc, row0, col0, true, full);
 #ifdef VB_GEMM_LAB
         if (tl != nullptr && threadIdx.x == 0 && it < 6) p.dbg[8 * 65536 + 16 * (long)blockIdx.x + 5 + 2 * it] = wall_clock64();
 #endif
