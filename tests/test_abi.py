@@ -135,6 +135,18 @@ def test_gemm_kernels_keep_their_register_budget(native):
     assert seen > 20
 
 
+def test_short_sequence_attention_forward_keeps_three_blocks_per_cu(native):
+    """attn_q_lds_kernel<128, false> stages K and V of a (sample, head) in 50.7 KB of LDS: three blocks fit a CU, so the
+    kernel is built for three waves per SIMD (__launch_bounds__(256, 3)): VGPRs + AGPRs <= 168. Batching its staging loads
+    (round 3) pushed the unconstrained build to 170 registers = two blocks per CU."""
+    text = open(os.path.join(os.path.dirname(native.LIB_PATH), "attention.resource.txt")).read()
+    found = re.findall(r"Function Name: \S*attn_q_lds_kernelILi128ELb0E\S*.*?VGPRs: (\d+).*?AGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
+                       text, flags=re.S)
+    assert found, "kernel not found in attention.resource.txt"
+    vgprs, agprs, occ = (int(v) for v in found[0])
+    assert vgprs + agprs <= 168 and occ >= 3, (vgprs, agprs, occ)
+
+
 def test_gemm_mode_names_round_trip_without_a_gpu(native):
     """Mode selection is host state (C side: arithmetic of vb_linear_*; Python side: the fp8 forward switch)."""
     first = native.set_gemm_mode("f32")
