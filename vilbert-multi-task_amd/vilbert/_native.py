@@ -285,8 +285,16 @@ def check(code, what):
 
 # torch.cuda.current_stream() builds a Stream object through several layers of Python (~3.5 us, and an eager step at
 # 64 samples asks for the stream ~1,400 times: tools/host_profile.py); these two go straight to the C++ getters.
-_cuda_raw_stream = torch._C._cuda_getCurrentRawStream
-_cuda_device = torch._C._cuda_getDevice
+# (private torch entry points, present in the PyTorch 2.x builds this package targets; a build without them gets the
+# public API - same results, slower)
+_cuda_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cuda_device = getattr(torch._C, "_cuda_getDevice", None)
+_cuda_set_stream = getattr(torch._C, "_cuda_setStream", None)
+if _cuda_raw_stream is None or _cuda_device is None:
+    _cuda_device = torch.cuda.current_device
+
+    def _cuda_raw_stream(device_index):
+        return torch.cuda.current_stream(device_index).cuda_stream
 
 
 def current_device():
@@ -300,7 +308,10 @@ def raw_stream(device_index=None):
 
 def set_stream(st):
     """Make the torch.cuda.Stream `st` current (torch.cuda.set_stream without its Python layers)."""
-    torch._C._cuda_setStream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+    if _cuda_set_stream is None:
+        torch.cuda.set_stream(st)
+    else:
+        _cuda_set_stream(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
 
 
 def stream_ptr():
