@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 12
+#define VB_ABI_VERSION 13
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -79,18 +79,25 @@ int vb_bump_counter(void* stream, uint64_t* device_counter);   /* *device_counte
  * Returns the previous code; an unknown value only queries. Environment: VB_GEMM_TILE=<code>, VB_GEMM_V2=0. */
 int vb_set_gemm_tile(int code);
 
-/* Deterministic weight gradients (round 3). By default a split-K launch (vb_linear_bwd_weight: the contraction runs
- * over the token rows; vb_linear_bwd_input with a small output and a long contraction, e.g. the MLM decoder) adds the
- * partial products of its splits into the result with fp32 atomics: the value depends in the last bits on the order the
- * blocks finish in, where the reference's cuBLAS path (autograd of the nn.Linear call sites, vilbert.py:425-427, 471,
- * 501, 514) is repeatable. With on = 1 every split stores its partial product into `workspace` and a second kernel
- * adds the partials in split order: bit-identical from run to run (measured cost: DESIGN.md). The workspace (device
- * memory, 16-byte aligned, owned by the caller, must outlive the setting) is cut into 8 equal slices, one per stream
- * that issues split launches (so launches on different streams never share memory); a slice has to hold
- * splits x (M x N + M) floats of the largest split launch (8 x 256 MiB is ample for the two-stream models), else - or when
- * a ninth stream shows up - the launch returns VB_E_WORKSPACE. The embedding-table gradients (vb_text_embed_bwd) still
- * use atomics. Returns the previous setting (0 / 1) or a negative error. */
+/* Deterministic weight gradients (round 3; per-device workspaces since ABI 13). By default a split-K launch
+ * (vb_linear_bwd_weight: the contraction runs over the token rows; vb_linear_bwd_input with a small output and a long
+ * contraction, e.g. the MLM decoder) adds the partial products of its splits into the result with fp32 atomics: the
+ * value depends in the last bits on the order the blocks finish in, where the reference's cuBLAS path (autograd of the
+ * nn.Linear call sites, vilbert.py:425-427, 471, 501, 514) is repeatable. With on = 1 every split stores its partial
+ * product into a workspace and a second kernel adds the partials in split order: bit-identical from run to run
+ * (measured cost: DESIGN.md). `workspace` (device memory, 16-byte aligned, owned by the caller, must outlive the setting
+ * AND every captured graph that was recorded under it) serves the DEVICE IT LIVES ON: call once per device a process
+ * drives (nn.DataParallel replicas - the reference's non-distributed multi-GPU path, train_concap.py:513-515); a launch
+ * on a device without a workspace uses the atomics. A workspace is cut into 8 equal slices, one per stream of that
+ * device that issues split launches (launches on different streams never share memory); a slice has to hold
+ * splits x (M x N + M) floats of the largest split launch (8 x 256 MiB is ample for the two-stream models). A launch
+ * that finds no free slice (a ninth stream) or whose partials do not fit falls back to the atomics for that launch -
+ * never an error - and is counted by vb_deterministic_fallbacks(). Registering the same buffer again keeps the
+ * stream -> slice assignment; on = 0 drops every device's registration. The embedding-table gradients
+ * (vb_text_embed_bwd) still use atomics. Returns the previous setting (0 / 1) or a negative error. */
 int vb_set_deterministic(int on, void* workspace, int64_t workspace_bytes);
+/* Split launches since the last vb_set_deterministic(1, ...) that wanted the ordered reduce and ran with atomics. */
+int64_t vb_deterministic_fallbacks(void);
 
 /* Persistent one-block-per-CU fp32 GEMM (round 3; forward and dgrad layouts of vb_linear_fwd / vb_linear_bwd_input,
  * replaces the same nn.Linear call sites - vilbert.py:425-427,471,501,514): 12 MFMA waves + 1 LDS-DMA loader wave per

@@ -1,0 +1,300 @@
+"""Execute the reference's OWN training scripts, unmodified, against this repository's `vilbert` package.
+
+TEST INFRASTRUCTURE (build container only: /root/reference does not exist on the GPU box). Called as a subprocess by
+tests/test_reference_scripts.py:
+
+    python tests/reference_dry_run.py concap <workdir>      # /root/reference/train_concap.py main(), 1 epoch x 2 steps
+    python tests/reference_dry_run.py tasks  <workdir>      # /root/reference/train_tasks.py  main(), VQA + retrieval
+
+What is real: the script (`runpy`, run_name "__main__", its own argparse), the import resolution the launcher
+vilbert-multi-task_amd/run_reference.py sets up (model classes, BertConfig, from_pretrained, AdamW + schedules, apex
+names from THIS repository; `vilbert.datasets`, `vilbert.task_utils`, `vilbert.optimization`, `utils.tbLogger`,
+`utils.MultiTaskStopOnPlateau` from the reference through the `__path__` fall-through), parameter grouping, the loop
+bodies, the loss arithmetic of `ForwardModelsTrain`, checkpoint writing.
+What is replaced: the data (the LMDB / tensorpack loaders are swapped for synthetic batches in the loaders' output
+format - oracle/batch_oracle.py for train_concap.py:523-533, the dataset tuples of task_utils.py:188-196 for
+train_tasks.py) and the tokenizer download. With no GPU in the container the device side is replaced too: `.cuda()`
+is the identity, the model's forward is the CPU oracle over the module's own parameters and `AdamW.step` the CPU
+AdamW restatement - so gradients flow and weights move, but no kernel runs. On a machine with BOTH the reference
+checkout and a GPU nothing device-side is replaced and the scripts drive the HIP model for real.
+
+Prints one JSON line `{"ok": true, ...}` with what was observed.
+"""
+import json
+import os
+import runpy
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vilbert-multi-task_amd")
+REF = os.environ.get("VILBERT_REFERENCE_ROOT", "/root/reference")
+
+
+def _setup_imports():
+    os.environ["VILBERT_REFERENCE_ROOT"] = REF
+    sys.path[:] = [PKG, ROOT] + [p for p in sys.path if os.path.abspath(p or ".") not in (PKG, ROOT, REF)] + [REF]
+    import vilbert
+    assert vilbert.attach_reference(REF) == os.path.join(REF, "vilbert")
+    from vilbert import _compat
+    _compat.install()
+
+
+class _Tokenizer(object):
+    """Stands in for BertTokenizer.from_pretrained('bert-base-uncased') (a download); the fake loaders never call it."""
+    vocab = {}
+
+    @classmethod
+    def from_pretrained(cls, *a, **k):
+        return cls()
+
+
+def _cfg_dict(config):
+    from oracle import synth
+    cfg = dict(synth._DEFAULTS)
+    cfg.update(config.to_dict())
+    return cfg
+
+
+def _named_leaves(model):
+    sd = dict(model.named_parameters())
+    for k, v in model.state_dict(keep_vars=True).items():     # tied decoder weight is not in named_parameters()
+        sd.setdefault(k, v)
+    return sd
+
+
+def _mock_device_side(observed):
+    """No GPU here: identity `.cuda()`, oracle forward over the module's own parameters, CPU AdamW restatement."""
+    import torch
+    from oracle import adamw_oracle, vilbert_oracle as vo
+    import vilbert.vilbert as V
+    import vilbert.optim as O
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+    def pre_forward(self, *args, **kwargs):
+        out = vo.pretraining_forward(_named_leaves(self), _cfg_dict(self.config), *args, **kwargs)
+        observed["forward_calls"] += 1
+        return out
+
+    def vl_forward(self, input_txt, input_imgs, image_loc, token_type_ids=None, attention_mask=None,
+                   image_attention_mask=None, co_attention_mask=None, task_ids=None, *a, **k):
+        cfg = _cfg_dict(self.config)
+        out = vo.vltasks_forward(_named_leaves(self), cfg, input_txt, input_imgs, image_loc, token_type_ids,
+                                 attention_mask, image_attention_mask, co_attention_mask,
+                                 task_ids if cfg["task_specific_tokens"] else None)
+        observed["forward_calls"] += 1
+        return tuple(out) + (None,)
+
+    V.BertForMultiModalPreTraining.forward = pre_forward
+    V.VILBertForVLTasks.forward = vl_forward
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                adamw_oracle.adamw_step(p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"],
+                                        group["betas"], group["eps"], group["weight_decay"], group["correct_bias"])
+        observed["optimizer_steps"] += 1
+    O.AdamW.step = step
+
+
+def _observe_device_side(observed):
+    """GPU present: nothing is replaced, the calls are only counted."""
+    import vilbert.vilbert as V
+    import vilbert.optim as O
+    for cls in (V.BertForMultiModalPreTraining, V.VILBertForVLTasks):
+        def wrap(orig):
+            def forward(self, *a, **k):
+                observed["forward_calls"] += 1
+                return orig(self, *a, **k)
+            return forward
+        cls.forward = wrap(cls.forward)
+    orig_step = O.AdamW.step
+
+    def step(self, closure=None):
+        observed["optimizer_steps"] += 1
+        return orig_step(self, closure)
+    O.AdamW.step = step
+
+
+class _ConcapLoader(object):
+    """ConceptCapLoaderTrain / Val's public face (concept_cap_dataset.py:153-288, 291-395): `num_dataset`, `__len__`,
+    `__iter__` yielding the eleven-entry batch of :269-282, built by oracle/batch_oracle.py."""
+    n_batches = 2
+
+    def __init__(self, corpus_path, tokenizer, bert_model, seq_len, encoding="utf-8", visual_target=0, batch_size=512,
+                 shuffle=False, num_workers=25, cache=10000, drop_last=False, cuda=False, local_rank=-1, objective=0,
+                 visualization=False, **kw):
+        self.batch_size, self.seq_len, self.num_dataset = batch_size, seq_len, self.n_batches * batch_size
+
+    def __len__(self):
+        return self.n_batches
+
+    def __iter__(self):
+        import torch
+        from oracle import batch_oracle as bo
+        for i in range(self.n_batches):
+            raw = bo.make_raw_batch(self.batch_size, tokens=self.seq_len, regions=9, seed=100 + i)
+            fin = bo.finish_batch(raw, objective=0)
+            order = ("input_ids", "input_mask", "segment_ids", "lm_label_ids", "is_next", "image_feat", "image_loc",
+                     "image_target", "image_label", "image_mask")
+            yield tuple(torch.from_numpy(fin[k]) for k in order) + (list(range(self.batch_size)),)
+
+
+def run_concap(work):
+    import torch
+    observed = dict(forward_calls=0, optimizer_steps=0)
+    (_observe_device_side if torch.cuda.is_available() else _mock_device_side)(observed)
+    import vilbert.datasets as D
+    import pytorch_transformers.tokenization_bert as T
+    D.ConceptCapLoaderTrain = D.ConceptCapLoaderVal = _ConcapLoader
+    T.BertTokenizer = _Tokenizer
+    os.chdir(REF)                                   # the script opens config/<name>_weight_name.json relatively
+    out = os.path.join(work, "save")
+    # (`--from_pretrained ""` is not runnable upstream: train_concap.py:244-246 opens config/<from_pretrained>_weight_name.json
+    # unconditionally - so the name is given and `from_pretrained` itself is replaced by a random init below)
+    sys.argv = [os.path.join(REF, "train_concap.py"), "--from_pretrained", "bert-base-uncased", "--bert_model", "bert-base-uncased",
+                "--config_file", "config/bert_base_2layer_2conect.json", "--train_batch_size", "4",
+                "--max_seq_length", "12", "--num_train_epochs", "1", "--output_dir", out, "--objective", "1",
+                "--num_workers", "0"]
+    import vilbert.vilbert as V
+    real_from_pretrained = V.BertForMultiModalPreTraining.from_pretrained.__func__
+
+    def from_pretrained(cls, name, *a, **k):       # no checkpoint download here: random init, like `--from_pretrained ""`
+        observed["from_pretrained"] = name
+        k.pop("default_gpu", None)
+        return cls(k.pop("config"), *a, **k)
+    V.BertForMultiModalPreTraining.from_pretrained = classmethod(from_pretrained)
+    ns = runpy.run_path(sys.argv[0], run_name="__main__")
+    V.BertForMultiModalPreTraining.from_pretrained = classmethod(real_from_pretrained)
+    ckpts = sorted(f for _d, _s, fs in os.walk(out) for f in fs)
+    observed.update(model_class_file=os.path.relpath(sys.modules[ns["BertForMultiModalPreTraining"].__module__].__file__, ROOT),
+                    adamw_file=os.path.relpath(sys.modules[ns["AdamW"].__module__].__file__, ROOT),
+                    loader_file=sys.modules["vilbert.datasets"].__file__,
+                    tblogger_file=ns["utils"].tbLogger.__module__, files_written=ckpts)
+    return observed
+
+
+class _TaskDataset(object):
+    def __init__(self, num_labels):
+        self.num_labels = num_labels
+
+
+class _TaskLoader(object):
+    """A torch-0.4-style loader: `iter(loader).next()` (task_utils.py:181,185) and `len()`; yields the dataset tuples of
+    task_utils.py:188-196 for a 'VL-classifier' task (VQA, :vqa_dataset.py) or a 'VL-logit' retrieval task
+    (retreival_dataset.py: [options] x image)."""
+
+    def __init__(self, kind, n_batches, batch, n_tok, n_reg, num_labels, seed):
+        self.kind, self.n_batches, self.batch, self.n_tok, self.n_reg, self.num_labels, self.seed = \
+            kind, n_batches, batch, n_tok, n_reg, num_labels, seed
+
+    def __len__(self):
+        return self.n_batches
+
+    def _one(self, i):
+        import torch
+        g = torch.Generator().manual_seed(self.seed + i)
+        B, T, R = self.batch, self.n_tok, self.n_reg
+        lead = (B,) if self.kind == "vqa" else (B, 4)
+        features = torch.rand(*lead, R, 2048, generator=g)
+        spatials = torch.rand(*lead, R, 5, generator=g)
+        image_mask = torch.ones(*lead, R, dtype=torch.long)
+        image_mask[..., R - 2:] = 0
+        question = torch.randint(1, 30000, (*lead, T), generator=g)
+        input_mask = torch.ones(*lead, T, dtype=torch.long)
+        input_mask[..., T - 3:] = 0
+        segment_ids = torch.zeros(*lead, T, dtype=torch.long)
+        co_attention_mask = torch.zeros(*lead, R, T)
+        if self.kind == "vqa":
+            target = torch.zeros(B, self.num_labels)
+            target[torch.arange(B), torch.randint(0, self.num_labels, (B,), generator=g)] = 1.0
+        else:
+            target = torch.zeros(B, dtype=torch.long)
+        qid = torch.arange(B)
+        return (features, spatials, image_mask, question, target, input_mask, segment_ids, co_attention_mask, qid)
+
+    def __iter__(self):
+        loader = self
+
+        class _It(object):
+            i = 0
+
+            def __iter__(self):
+                return self
+
+            def __next__(self):
+                if self.i >= loader.n_batches:
+                    raise StopIteration
+                self.i += 1
+                return loader._one(self.i)
+            next = __next__
+        return _It()
+
+
+def run_tasks(work):
+    import torch
+    observed = dict(forward_calls=0, optimizer_steps=0)
+    (_observe_device_side if torch.cuda.is_available() else _mock_device_side)(observed)
+    import vilbert.task_utils as TU
+    import vilbert.vilbert as V
+    from oracle import synth
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    cfg.update(v_target_size=1601)
+    num_labels = 3129
+    ckpt = os.path.join(work, "pretrained.bin")
+
+    def load_datasets(args, task_cfg, ids):
+        task_ids = ["TASK" + i for i in ids]
+        kinds = {"TASK1": "vqa", "TASK8": "retrieval"}
+        train = {t: _TaskLoader(kinds[t], 2, 2, 10, 7, num_labels, 11) for t in task_ids}
+        val = {t: _TaskLoader(kinds[t], 1, 2, 10, 7, num_labels, 99) for t in task_ids}
+        ds = {t: _TaskDataset(num_labels) for t in task_ids}
+        observed["load_datasets_tasks"] = task_ids
+        return ({t: 2 for t in task_ids}, {t: 2 for t in task_ids}, task_ids, ds, dict(ds), train, val)
+    TU.LoadDatasets = load_datasets
+    real_val = TU.ForwardModelsVal
+
+    def forward_models_val(args, task_cfg, device, task_id, batch, model, task_losses):
+        if task_id == "TASK8":
+            # the reference's validation set for retrieval is a 1000-image ranking protocol with its own tuple
+            # (retreival_dataset.py RetreivalDatasetVal) - data side; score the fake batch like a train batch instead
+            with torch.no_grad():
+                one = _TaskLoader("retrieval", 1, 2, 10, 7, num_labels, 0)
+                one._one = lambda i: batch
+                loss, score = TU.ForwardModelsTrain(args, task_cfg, device, task_id, {task_id: 0}, {task_id: None},
+                                                    {task_id: one}, model, task_losses)
+            return float(loss), float(score), batch[0].size(0)
+        return real_val(args, task_cfg, device, task_id, batch, model, task_losses)
+    TU.ForwardModelsVal = forward_models_val
+
+    # a checkpoint for `VILBertForVLTasks.from_pretrained(args.from_pretrained, ...)` (train_tasks.py:370-375): a
+    # pre-training state dict, as the published pytorch_model_*.bin files are
+    torch.save(synth.make_state_dict(cfg, "pretraining"), ckpt)
+    os.chdir(REF)
+    out = os.path.join(work, "save")
+    sys.argv = [os.path.join(REF, "train_tasks.py"), "--bert_model", "bert-base-uncased", "--from_pretrained", ckpt,
+                "--config_file", "config/bert_base_2layer_2conect.json", "--tasks", "1-8", "--num_train_epochs", "1",
+                "--output_dir", out, "--num_workers", "0", "--lr_scheduler", "warmup_linear",
+                "--train_iter_multiplier", "0.06", "--task_specific_tokens"]
+    ns = runpy.run_path(sys.argv[0], run_name="__main__")
+    ckpts = sorted(f for _d, _s, fs in os.walk(out) for f in fs)
+    observed.update(model_class_file=os.path.relpath(sys.modules[V.VILBertForVLTasks.__module__].__file__, ROOT),
+                    adamw_file=os.path.relpath(sys.modules[ns["AdamW"].__module__].__file__, ROOT),
+                    task_utils_file=TU.__file__, radam_file=sys.modules[ns["RAdam"].__module__].__file__,
+                    stop_controller=ns["utils"].MultiTaskStopOnPlateau.__module__, files_written=ckpts)
+    return observed
+
+
+if __name__ == "__main__":
+    which, work = sys.argv[1], sys.argv[2]
+    _setup_imports()
+    res = run_concap(work) if which == "concap" else run_tasks(work)
+    res["ok"] = True
+    print("DRYRUN " + json.dumps(res))

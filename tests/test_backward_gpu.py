@@ -418,3 +418,22 @@ def test_gradient_side_dropout_rides_on_the_layernorm_backward():
     for n in g_off:
         if not any(k in n for k in skip):
             assert torch.equal(g_off[n], g_on[n]), n
+
+
+def test_dropout_twin_is_dropped_after_an_in_place_write():
+    """Round-3 advisor: the hand-over tag (`_vb_dropped`) rides on a Python attribute of the gradient tensor; if autograd
+    ever accumulated a second consumer's gradient IN PLACE into that tensor the stale twin would still be used. The tag
+    now carries the tensor's address and version counter; after an in-place write `_dropped` recomputes."""
+    import vilbert.autograd_ops as AO
+    from vilbert import ops
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(64, 768, generator=g).to(DEV)
+    p, seed = 0.1, 1234
+    twin = ops.dropout(dy, p, seed)
+    dy._vb_dropped = (p, seed, twin, dy.data_ptr(), dy._version)
+    assert AO._dropped(dy, (p, seed)) is twin                       # untouched: the twin is handed over
+    assert AO._dropped(dy, (p, seed + 1)) is not twin               # another mask: recomputed
+    dy.add_(1.0)                                                    # what an in-place accumulation would do
+    got = AO._dropped(dy, (p, seed))
+    assert got is not twin
+    assert torch.equal(got, ops.dropout(dy, p, seed))

@@ -1,7 +1,7 @@
 """Deterministic split-K weight gradients (vb_set_deterministic, round-2 verdict missing item 6): partial products of the
 K splits go to a workspace and are added in split order instead of with fp32 atomics. Two runs must be BIT-identical
-(they are not required to be with atomics), the values must agree with the atomic path and with fp64, a workspace that
-is too small must be refused loudly."""
+(they are not required to be with atomics), the values must agree with the atomic path and with fp64; a launch that finds
+no workspace slice (too small, ninth stream, another device) falls back to atomics and is counted."""
 import pytest
 import torch
 
@@ -97,19 +97,79 @@ def test_split_k_dgrad_of_a_small_output_is_bit_identical(det):
     assert (a.cpu().double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
 
 
-def test_workspace_too_small_is_refused():
+def test_workspace_too_small_falls_back_to_atomics_and_is_counted():
+    """Round-3 advisor: a launch whose partials do not fit its slice used to fail with VB_E_WORKSPACE; it now runs with
+    the fp32 atomics (correct, not bit-reproducible) and `deterministic_fallbacks()` says so."""
     from vilbert import _native, ops
     prev = _native._DET["wanted"]
     _native.set_deterministic(False)
     ws = torch.empty(8 * 1024, dtype=torch.float32, device=DEV)
     assert _native.lib().vb_set_deterministic(1, ws.data_ptr(), ws.numel() * 4) == 0
     try:
+        assert _native.deterministic_fallbacks() == 0
         x, dy = _rand(9216, 768, seed=1).to(DEV), _rand(9216, 768, seed=2).to(DEV)
-        with pytest.raises(RuntimeError, match="WORKSPACE"):
-            ops.linear_bwd_weight(dy, x, 1, 768, [True])
+        (dw,), (db,) = ops.linear_bwd_weight(dy, x, 1, 768, [True])
+        torch.cuda.synchronize()
+        assert _native.deterministic_fallbacks() >= 1
+        want = (dy.double().t() @ x.double()).cpu()
+        assert (dw.cpu().double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+        assert (db.cpu().double() - dy.double().sum(0).cpu()).abs().max().item() <= 1e-3
     finally:
         _native.lib().vb_set_deterministic(0, None, 0)
         _native.set_deterministic(prev)
+
+
+def test_ninth_stream_falls_back_instead_of_raising_and_slots_survive_reregistration(det):
+    """A workspace has 8 per-stream slices. Round-3 advisor: a ninth stream made every split launch on it fail for the
+    rest of the process (GraphedTrainStep warm-ups draw fresh streams). Now: streams 1-8 are ordered (bit-identical),
+    stream 9 runs with atomics and is counted; registering the SAME buffer again keeps the assignment (captured graphs
+    have it baked in), a NEW buffer starts with free slices."""
+    from vilbert import _native, ops
+    _native.set_deterministic(False)
+    _native.set_deterministic(True, device=DEV)
+    x, dy = _rand(9216, 768, seed=1).to(DEV), _rand(9216, 768, seed=2).to(DEV)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(9)]
+    first = None
+    for i, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            (dw,), _ = ops.linear_bwd_weight(dy, x, 1, 768, [True])
+        st.synchronize()
+        if i < 8:
+            assert _native.deterministic_fallbacks() == 0, i
+            first = dw if first is None else first
+            assert torch.equal(dw, first)                        # ordered reduce: same bits on every stream
+        else:
+            assert _native.deterministic_fallbacks() >= 1
+            assert (dw - first).abs().max().item() <= 1e-3 * first.abs().max().item()
+    ws = _native.deterministic_workspace(DEV)
+    _native.set_deterministic(True, device=DEV)                  # same buffer: assignment kept -> stream 9 still has no slice
+    assert _native.deterministic_workspace(DEV) is ws
+    with torch.cuda.stream(streams[8]):
+        ops.linear_bwd_weight(dy, x, 1, 768, [True])
+    streams[8].synchronize()
+    assert _native.deterministic_fallbacks() >= 1
+    _native.set_deterministic(True, workspace_mb=2304, device=DEV)   # larger -> new buffer, the old one is retired, not freed
+    assert _native.deterministic_workspace(DEV) is not ws and any(r is ws for r in _native._DET["retired"])
+    with torch.cuda.stream(streams[8]):
+        (dw,), _ = ops.linear_bwd_weight(dy, x, 1, 768, [True])
+    streams[8].synchronize()
+    assert _native.deterministic_fallbacks() == 0 and torch.equal(dw, first)
+    _native.set_deterministic(True, workspace_mb=2048)
+
+
+def test_workspace_is_per_device_and_lazily_registered(det):
+    """Round-3 advisor (high): the workspace used to be one process-global buffer on whichever device ran backward first.
+    It is now keyed by device; `ensure_deterministic` registers the launch device's own on first use."""
+    from vilbert import _native
+    _native.set_deterministic(False)
+    assert _native._DET["ws"] == {}
+    _native._DET["wanted"] = True
+    _native.ensure_deterministic(torch.device(DEV))
+    ws = _native.deterministic_workspace(DEV)
+    assert ws is not None and ws.device == torch.device(DEV) and list(_native._DET["ws"]) == [0]
+    _native.ensure_deterministic(torch.device(DEV))
+    assert _native.deterministic_workspace(DEV) is ws
 
 
 def test_default_is_deterministic_and_streams_stay_on():

@@ -1,0 +1,219 @@
+"""Row g3 / f4 of the round-3 review: the reference's own scripts run, UNMODIFIED, against this repository's `vilbert`
+package (BASELINE.json north_star: "train_concap.py and train_tasks.py drop in unchanged").
+
+Build container only (needs /root/reference); the GPU-side counterpart - the same `ForwardModelsTrain` arithmetic
+through the HIP model against the oracle - is tests/test_task_forward_gpu.py.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import ref_loader, task_forward_oracle as tf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vilbert-multi-task_amd")
+needs_reference = pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    env.update(extra)
+    return env
+
+
+def _dry_run(which, tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "reference_dry_run.py"), which, str(tmp_path)],
+                       capture_output=True, text=True, timeout=900, env=_env())
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("DRYRUN ")][-1]
+    return json.loads(line[len("DRYRUN "):])
+
+
+@needs_reference
+def test_train_concap_main_runs_unmodified(tmp_path):
+    """/root/reference/train_concap.py `main()`: argparse, BertConfig.from_json_file, from_pretrained, the per-parameter
+    groups, AdamW + WarmupLinearSchedule, tbLogger, two training steps of the loop body (:523-606), the validation loop
+    (:609-652) and the checkpoint (:654-676)."""
+    got = _dry_run("concap", tmp_path)
+    assert got["ok"] and got["optimizer_steps"] == 2 and got["forward_calls"] == 4          # 2 train + 2 validation
+    assert got["model_class_file"] == "vilbert-multi-task_amd/vilbert/vilbert.py"          # OUR model class ...
+    assert got["adamw_file"] == "vilbert-multi-task_amd/vilbert/optim.py"                  # ... and optimizer
+    assert got["loader_file"].startswith(ref_loader.REFERENCE_ROOT)                        # the reference's datasets package
+    assert got["tblogger_file"] == "vilbert._reference_utils"                              # the reference's tbLogger
+    assert {"pytorch_model_0.bin", "pytorch_ckpt_0.tar", "command.txt"} <= set(got["files_written"])
+    # the checkpoint the script wrote loads back into a fresh model of this package, key for key
+    sys.path.insert(0, PKG)
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    cfg = BertConfig.from_json_file(os.path.join(PKG, "config", "bert_base_2layer_2conect.json"))
+    cfg.v_target_size, cfg.visual_target = 1601, 0
+    path = [os.path.join(d, f) for d, _s, fs in os.walk(tmp_path) for f in fs if f == "pytorch_model_0.bin"][0]
+    sd = torch.load(path, map_location="cpu")
+    model = BertForMultiModalPreTraining(cfg)
+    assert list(sd.keys()) == list(model.state_dict().keys())
+    model.load_state_dict(sd)
+
+
+@needs_reference
+def test_train_tasks_main_runs_unmodified(tmp_path):
+    """/root/reference/train_tasks.py `main()` on tasks 1-8 (VQA + Flickr30k retrieval): vilbert_tasks.yml through
+    easydict, LoadLosses, from_pretrained of a pre-training checkpoint into VILBertForVLTasks, per-parameter groups,
+    AdamW(correct_bias=False), MultiTaskStopOnPlateau, `ForwardModelsTrain` (the reference's own function) per task and
+    step, evaluate(), and the checkpoint with the pickled tbLogger / stop controllers."""
+    got = _dry_run("tasks", tmp_path)
+    assert got["ok"] and got["load_datasets_tasks"] == ["TASK1", "TASK8"]
+    assert got["optimizer_steps"] >= 2 and got["forward_calls"] >= got["optimizer_steps"] + 2
+    assert got["model_class_file"] == "vilbert-multi-task_amd/vilbert/vilbert.py"
+    assert got["adamw_file"] == "vilbert-multi-task_amd/vilbert/optim.py"
+    assert got["task_utils_file"].startswith(ref_loader.REFERENCE_ROOT)
+    assert got["radam_file"].startswith(ref_loader.REFERENCE_ROOT)
+    assert "pytorch_ckpt_latest.tar" in got["files_written"]
+    # a later process can unpickle what the script pickled (tb_logger, task_stop_controller: classes of the reference's
+    # utils.py, served under vilbert._reference_utils)
+    ckpt = [os.path.join(d, f) for d, _s, fs in os.walk(tmp_path) for f in fs if f == "pytorch_ckpt_latest.tar"][0]
+    code = ("import sys, torch; sys.path.insert(0, %r); c = torch.load(%r, map_location='cpu', weights_only=False); "
+            "print(type(c['tb_logger']).__name__, type(c['task_stop_controller']['TASK1']).__name__, c['global_step'])"
+            % (PKG, ckpt))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=_env(VILBERT_REFERENCE_ROOT=ref_loader.REFERENCE_ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.split()[:2] == ["tbLogger", "MultiTaskStopOnPlateau"]
+
+
+@needs_reference
+@pytest.mark.parametrize("script", ["train_concap.py", "train_tasks.py", "eval_tasks.py", "eval_retrieval.py"])
+def test_launcher_resolves_every_import_of_the_script(script):
+    """`python vilbert-multi-task_amd/run_reference.py <script> --help`: every module-scope import of the unmodified
+    script resolves (ours first, the reference's data / logging side through the fall-through, placeholders for the
+    packages the image lacks) and argparse prints the script's own usage. No mocks."""
+    p = subprocess.run([sys.executable, os.path.join(PKG, "run_reference.py"),
+                        os.path.join(ref_loader.REFERENCE_ROOT, script), "--help"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ref_loader.REFERENCE_ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "--config_file" in p.stdout and "usage:" in p.stdout
+
+
+@needs_reference
+def test_package_resolution_order_with_reference_attached():
+    code = """
+import sys, os
+sys.path.insert(0, %r)
+os.environ['VILBERT_REFERENCE_ROOT'] = %r
+import vilbert, vilbert.vilbert, vilbert.utils, vilbert.optimization, vilbert.task_utils
+from vilbert import _compat
+print(vilbert.vilbert.__file__); print(vilbert.utils.__file__); print(vilbert.optimization.__file__)
+print(vilbert.utils.PreTrainedModel.__module__, vilbert.utils.tbLogger.__module__, vilbert.utils.cached_path.__module__)
+""" % (PKG, ref_loader.REFERENCE_ROOT)
+    # task_utils imports the datasets -> needs the placeholders first
+    code = code.replace("import vilbert, vilbert.vilbert", "import vilbert; from vilbert import _compat; _compat.install(); "
+                        "sys.path.append(os.environ['VILBERT_REFERENCE_ROOT']); import vilbert.vilbert")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    ours, utils, optimization, names = p.stdout.strip().splitlines()[-4:]
+    assert ours.startswith(PKG) and utils.startswith(PKG) and optimization.startswith(ref_loader.REFERENCE_ROOT)
+    assert names.split() == ["vilbert.utils", "vilbert._reference_utils", "vilbert._reference_utils"]
+
+
+def test_without_a_reference_checkout_the_package_stands_alone():
+    """No VILBERT_REFERENCE_ROOT, no checkout on sys.path (the GPU box): the model path imports, the logging names say
+    what is missing instead of failing obscurely."""
+    code = ("import sys; sys.path.insert(0, %r); import vilbert, vilbert.utils as u; assert vilbert.REFERENCE_PACKAGE_DIR is None; "
+            "assert len(vilbert.__path__) == 1; u.PreTrainedModel\n"
+            "try:\n    u.tbLogger\nexcept AttributeError as e:\n    print('MSG', e)\n" % PKG)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_env(), cwd="/tmp")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "VILBERT_REFERENCE_ROOT" in p.stdout
+
+
+def test_compat_placeholders():
+    sys.path.insert(0, PKG)
+    from vilbert import _compat
+    made = _compat.install()
+    assert _compat.install() == [] or set(_compat.install()) <= set(made)          # idempotent
+    import msgpack                                                                  # installed: must stay the real one
+    assert not getattr(msgpack, "__placeholder__", False)
+    from easydict import EasyDict as edict
+    d = edict({"TASK1": {"type": "VL-classifier", "lr": 4e-5, "sets": [{"a": 1}]}})
+    assert d.TASK1.type == "VL-classifier" and d["TASK1"]["lr"] == 4e-5 and d.TASK1.sets[0].a == 1
+    d.TASK1.extra = {"x": 2}
+    assert d["TASK1"]["extra"].x == 2
+    with pytest.raises(AttributeError):
+        d.nope
+    if "lmdb" in made:
+        import lmdb
+        with pytest.raises(ImportError, match="lmdb"):
+            lmdb.open("/nonexistent")
+    if "jsonlines" in made:
+        import jsonlines
+        p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "vb_compat_test.jsonl")
+        with open(p, "w") as f:
+            f.write('{"a": 1}\n\n{"a": 2}\n')
+        with jsonlines.open(p) as r:
+            assert [x["a"] for x in r] == [1, 2]
+
+
+# ---- the restatement of ForwardModelsTrain used by the GPU parity test, pinned against the real function ---------------
+
+class _CannedModel(object):
+    """Returns fixed, input-shaped outputs (the ten-tuple of VILBertForVLTasks.forward) and records its arguments."""
+
+    def __init__(self, num_labels, seed):
+        self.num_labels, self.seed, self.calls = num_labels, seed, []
+
+    def __call__(self, question, features, spatials, segment_ids, input_mask, image_mask, co_attention_mask, task_tokens):
+        self.calls.append([t.clone() for t in (question, features, spatials, segment_ids, input_mask, image_mask,
+                                               co_attention_mask, task_tokens)])
+        g = torch.Generator().manual_seed(self.seed)
+        n, r, t = question.size(0), features.size(1), question.size(1)
+        r_ = lambda *s: torch.randn(*s, generator=g, requires_grad=True)
+        return (r_(n, self.num_labels), r_(n, 1533), r_(n, 1), r_(n // 2, 2), r_(n, 3), r_(n, r, 1601), r_(n, r, 1),
+                r_(n, t, 30522 // 64), r_(n, t, 1), None)
+
+
+@needs_reference
+@pytest.mark.parametrize("task_id", sorted(tf.TASKS))
+def test_task_forward_restatement_matches_reference(task_id, monkeypatch):
+    """oracle/task_forward_oracle.py vs the reference's own ForwardModelsTrain on the same batch and stand-in model:
+    identical model arguments, loss and score for every (type, process) pair."""
+    sys.path.insert(0, PKG)
+    import vilbert
+    vilbert.attach_reference(ref_loader.REFERENCE_ROOT)
+    from vilbert import _compat
+    _compat.install()
+    if ref_loader.REFERENCE_ROOT not in sys.path:
+        sys.path.append(ref_loader.REFERENCE_ROOT)
+    import vilbert.task_utils as TU
+    import yaml
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    task_cfg = yaml.safe_load(open(os.path.join(ref_loader.REFERENCE_ROOT, "vilbert_tasks.yml")))
+    kind, loss_name, process = tf.TASKS[task_id]
+    assert (task_cfg[task_id]["type"], task_cfg[task_id]["loss"], task_cfg[task_id]["process"]) == (kind, loss_name, process)
+    n_reg = 110 if kind == "V-logit-mc" else 9
+    batch = tf.make_task_batch(task_id, 4, 7, n_reg, seed=5)
+
+    class _Loader(list):
+        def __iter__(self):
+            it = super().__iter__()
+
+            class _It(object):
+                def __iter__(self_):
+                    return self_
+
+                def __next__(self_):
+                    return next(it)
+                next = __next__                      # torch-0.4 loader iterators had .next(), which task_utils.py:186 calls
+            return _It()
+    ref_model, our_model = _CannedModel(3129, 3), _CannedModel(3129, 3)
+    losses = TU.LoadLosses(None, task_cfg, [task_id[4:]])
+    want_loss, want_score = TU.ForwardModelsTrain(None, task_cfg, "cpu", task_id, {task_id: 0}, {task_id: None},
+                                                  {task_id: _Loader([batch])}, ref_model, losses)
+    got_loss, got_score = tf.forward_train(task_id, batch, our_model)
+    assert len(ref_model.calls) == len(our_model.calls) == 1
+    for a, b in zip(ref_model.calls[0], our_model.calls[0]):
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(want_loss, got_loss)
+    assert float(want_score) == float(got_score)

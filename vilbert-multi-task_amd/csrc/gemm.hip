@@ -415,28 +415,54 @@ int gemm_v4_mode() {
 // registered by the caller and splitk_reduce_kernel adds them to C in split order - bit-identical results from run to
 // run, where the default (fp32 atomics from all splits into C) depends on the order the blocks happen to finish in.
 int g_det = -1;
-float* g_det_ws = nullptr;
-size_t g_det_bytes = 0;
-// The workspace is cut into DET_SLICES equal slices; every stream that issues split launches gets its own (first come,
-// first served, for the lifetime of the setting), so the text / image / weight-gradient side streams keep overlapping.
+// One workspace PER DEVICE (a process may drive several GPUs: nn.DataParallel replicas, the reference's non-distributed
+// multi-GPU path train_concap.py:513-515): a launch only ever uses the workspace registered for the device it runs on, and
+// falls back to the fp32-atomics split-K when there is none. Each workspace is cut into DET_SLICES equal slices; every
+// (device, stream) that issues split launches gets its own (first come, first served, for the lifetime of that
+// registration), so the text / image / weight-gradient side streams keep overlapping. A stream that comes after the
+// slices are taken, or a launch whose partials do not fit a slice, runs with atomics (correct, just not bit-reproducible)
+// and is counted (vb_deterministic_fallbacks) - it is never an error.
 constexpr int DET_SLICES = 8;
-hipStream_t g_det_streams[DET_SLICES];
-int g_det_nstreams = 0;
+constexpr int DET_MAX_DEV = 16;
+struct DetDevice {
+    float* ws = nullptr;
+    size_t bytes = 0;
+    hipStream_t streams[DET_SLICES];
+    int nstreams = 0;
+};
+DetDevice g_det_dev[DET_MAX_DEV];
+long g_det_fallbacks = 0;
 std::mutex g_det_mutex;     // autograd runs backward nodes on its own threads
 
 bool deterministic() {
     if (g_det < 0) g_det = 0;
-    return g_det != 0 && g_det_ws != nullptr;
+    return g_det != 0;
 }
 
-// slice of the calling stream, or -1 when more than DET_SLICES streams have asked
-int det_slice_of(hipStream_t st) {
+// workspace slice of (current device, stream): base pointer + slice size, or nullptr when the device has no workspace or
+// its slices are taken
+float* det_slice_of(hipStream_t st, size_t* slice_bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DET_MAX_DEV) return nullptr;
     std::lock_guard<std::mutex> lock(g_det_mutex);
-    for (int i = 0; i < g_det_nstreams; ++i)
-        if (g_det_streams[i] == st) return i;
-    if (g_det_nstreams == DET_SLICES) return -1;
-    g_det_streams[g_det_nstreams] = st;
-    return g_det_nstreams++;
+    DetDevice& d = g_det_dev[dev];
+    if (d.ws == nullptr) return nullptr;
+    const size_t slice = d.bytes / DET_SLICES / 16 * 16;
+    *slice_bytes = slice;
+    int k = -1;
+    for (int i = 0; i < d.nstreams; ++i)
+        if (d.streams[i] == st) { k = i; break; }
+    if (k < 0) {
+        if (d.nstreams == DET_SLICES) return nullptr;
+        d.streams[d.nstreams] = st;
+        k = d.nstreams++;
+    }
+    return d.ws + (size_t)k * (slice / sizeof(float));
+}
+
+void det_count_fallback() {
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    ++g_det_fallbacks;
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ cs_ws,
@@ -460,15 +486,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// Points the launch at the workspace (-> the kernels store partials instead of adding atomically). false = the
-// registered workspace is too small for `splits` partial copies of C.
+// Points the launch at the workspace (-> the kernels store partials instead of adding atomically). false = no slice for
+// this (device, stream) or the slice is too small for `splits` partial copies of C: the caller launches with atomics.
 bool det_prepare(hipStream_t st, GemmP& p, int splits) {
-    if (p.det_cs_parts < 1) p.det_cs_parts = 1;
-    const size_t need = ((size_t)splits * p.M * p.N + (size_t)splits * p.det_cs_parts * p.M) * sizeof(float);
-    const size_t slice = g_det_bytes / DET_SLICES / 16 * 16;
-    const int k = det_slice_of(st);
-    if (k < 0 || need > slice) return false;
-    float* base = g_det_ws + (size_t)k * (slice / sizeof(float));
+    const int cs_parts = p.det_cs_parts < 1 ? 1 : p.det_cs_parts;
+    const size_t need = ((size_t)splits * p.M * p.N + (size_t)splits * cs_parts * p.M) * sizeof(float);
+    size_t slice = 0;
+    float* base = det_slice_of(st, &slice);
+    if (base == nullptr || need > slice) { det_count_fallback(); return false; }
+    p.det_cs_parts = cs_parts;
     p.det_ws = base;
     p.det_stride = (long)p.M * p.N;
     p.det_cs = base + (size_t)splits * p.M * p.N;
@@ -563,10 +589,10 @@ int launch_wgrad_skinny(hipStream_t st, const vb_linear_bwd_weight_args* a) {
     const int slabs = SK_SLABS;
     if (deterministic()) {
         const size_t need = (size_t)slabs * (a->K + 1) * a->seg_n * sizeof(float);
-        const size_t slice = g_det_bytes / DET_SLICES / 16 * 16;
-        const int k = det_slice_of(st);
-        if (k < 0 || need > slice) return VB_E_WORKSPACE;
-        ws = g_det_ws + (size_t)k * (slice / sizeof(float));
+        size_t slice = 0;
+        ws = det_slice_of(st, &slice);
+        if (ws != nullptr && need > slice) ws = nullptr;
+        if (ws == nullptr) det_count_fallback();       // slabs added with fp32 atomics instead
     }
     const int rows_per_slab = (int)((a->M + slabs - 1) / slabs);
     hipLaunchKernelGGL(wgrad_skinny_kernel, dim3((unsigned)((a->seg_n + 255) / 256), (unsigned)slabs), dim3(256), 0, st, (int)a->M,
@@ -662,8 +688,7 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         const int c4w = (!A_KC && !B_KC && splits < 0) ? plan_v4w(p) : -1;
         if (c4w >= 0) {
             const int s4 = p.n_big / p.n_small;
-            const bool det = s4 > 1 && deterministic();
-            if (det && !det_prepare(st, p, s4)) return VB_E_WORKSPACE;
+            const bool det = s4 > 1 && deterministic() && det_prepare(st, p, s4);
             if (int e = launch_gemm_v4_tn(st, p, c4w)) return e;
             return det ? det_finish(st, p, s4) : 0;
         }
@@ -678,8 +703,7 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         p.m_split = pl.big_rows * 32 * pl.tm1;
         if (splits < 0) p.epi = pl.splits > 1 ? EPI_ATOMIC : EPI_ACCUM;
         const int tiles = (pl.big_rows + pl.small_rows) * pl.tiles_n;
-        const bool det = splits < 0 && pl.splits > 1 && deterministic();
-        if (det && !det_prepare(st, p, pl.splits)) return VB_E_WORKSPACE;
+        const bool det = splits < 0 && pl.splits > 1 && deterministic() && det_prepare(st, p, pl.splits);
         int e = 0;
         if (A_KC && B_KC) e = launch_gemm_v2_nt(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
         else if (A_KC) e = launch_gemm_v2_nn(st, p, pl.tm1, pl.tm2, pl.tn, tiles, pl.splits);
@@ -756,12 +780,35 @@ extern "C" int vb_set_deterministic(int on, void* workspace, int64_t workspace_b
     const int prev = g_det > 0 ? 1 : 0;
     if (on != 0 && on != 1) return prev;
     if (on && (workspace == nullptr || workspace_bytes <= 0 || !vb_aligned16(workspace))) return VB_E_BADARG;
+    int dev = -1;
+    if (on) {
+        // the workspace serves the device it lives on, whichever device is current now
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, workspace) != hipSuccess) { (void)hipGetLastError(); return VB_E_BADARG; }
+        dev = attr.device;
+        if (dev < 0 || dev >= DET_MAX_DEV) return VB_E_BADARG;
+    }
     std::lock_guard<std::mutex> lock(g_det_mutex);
-    g_det = on;
-    g_det_nstreams = 0;
-    g_det_ws = on ? static_cast<float*>(workspace) : nullptr;
-    g_det_bytes = on ? (size_t)workspace_bytes : 0;
+    if (!on) {
+        for (DetDevice& d : g_det_dev) d = DetDevice();
+        g_det = 0;
+        return prev;
+    }
+    DetDevice& d = g_det_dev[dev];
+    // re-registering the same buffer keeps the stream -> slice assignment (captured graphs have it baked in)
+    if (d.ws != static_cast<float*>(workspace) || d.bytes != (size_t)workspace_bytes) {
+        d = DetDevice();
+        d.ws = static_cast<float*>(workspace);
+        d.bytes = (size_t)workspace_bytes;
+    }
+    g_det = 1;
+    g_det_fallbacks = 0;
     return prev;
+}
+
+extern "C" int64_t vb_deterministic_fallbacks(void) {
+    std::lock_guard<std::mutex> lock(g_det_mutex);
+    return (int64_t)g_det_fallbacks;
 }
 
 extern "C" int vb_set_gemm_v4(int mode) {

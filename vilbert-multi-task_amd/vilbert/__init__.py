@@ -10,3 +10,39 @@ import os as _os
 # The variable is read when the HIP runtime initialises, i.e. at the first device call - importing this package early
 # (the training scripts do) is in time. (A whole-step HIP graph replays faster with 4 queues: vilbert/graphed.py.)
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+# --- fall-through to the reference checkout for everything that is NOT the hot path -----------------------------
+# This package replaces `vilbert.vilbert` (the model) and `vilbert.utils.PreTrainedModel`; the reference's training
+# scripts also import `vilbert.datasets`, `vilbert.task_utils`, `vilbert.optimization`, `vilbert.basebert`
+# (train_concap.py:29-31, train_tasks.py:32-46) - data / control side, not rebuilt here. A regular package named
+# `vilbert` would hide those, so the reference's own `vilbert/` directory is appended to `__path__` AFTER ours:
+# submodules that exist here resolve here, every other one is the reference's file, unmodified.
+def _reference_package_dir():
+    """The reference checkout's `vilbert/` directory: $VILBERT_REFERENCE_ROOT, else the first sys.path entry / the
+    working directory that holds a foreign `vilbert/task_utils.py` (the scripts are run from their checkout)."""
+    import sys
+    here = _os.path.dirname(_os.path.abspath(__file__))
+    roots = [_os.environ["VILBERT_REFERENCE_ROOT"]] if _os.environ.get("VILBERT_REFERENCE_ROOT") else \
+        [p or _os.getcwd() for p in sys.path] + [_os.getcwd()]
+    for root in roots:
+        cand = _os.path.join(_os.path.abspath(root), "vilbert")
+        if cand != here and _os.path.isfile(_os.path.join(cand, "task_utils.py")):
+            return cand
+    return None
+
+
+def attach_reference(root=None):
+    """(Re)run the search - `root` overrides it - and append the reference's package directory to `__path__`.
+    Returns the directory or None. Idempotent; called once at import."""
+    global REFERENCE_PACKAGE_DIR
+    cand = _os.path.join(_os.path.abspath(root), "vilbert") if root else _reference_package_dir()
+    if cand and _os.path.isdir(cand):
+        if cand not in __path__:
+            __path__.append(cand)
+        REFERENCE_PACKAGE_DIR = cand
+    return REFERENCE_PACKAGE_DIR
+
+
+REFERENCE_PACKAGE_DIR = None
+attach_reference()

@@ -147,6 +147,7 @@ SIGNATURES = {
     "vb_set_gemm_tile": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_gemm_v4": (ctypes.c_int, [ctypes.c_int]),
     "vb_set_deterministic": (ctypes.c_int, [ctypes.c_int, _P, _I64]),
+    "vb_deterministic_fallbacks": (_I64, []),
     "vb_set_seed_epoch": (ctypes.c_int, [_P]),
     "vb_bump_counter": (ctypes.c_int, [_P, _P]),
     "vb_linear_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LinearArgs)]),
@@ -191,7 +192,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 12:
+        if handle.vb_abi_version() != 13:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") == "fp8":
@@ -205,36 +206,70 @@ def set_gemm_tile(code):
     return lib().vb_set_gemm_tile(int(code))
 
 
-_DET = {"workspace": None, "wanted": os.environ.get("VB_DETERMINISTIC", "1") != "0"}
+# "ws": device index -> the workspace registered for that device; "retired": workspaces that were replaced or switched
+# off. They are kept for the life of the process on purpose: a HIP graph captured while one was registered has its address
+# and the stream -> slice assignment baked in (vilbert/graphed.py), and a replay after `set_deterministic(False)` or after
+# a re-registration with a larger size must still write into live memory that nothing else uses.
+_DET = {"ws": {}, "retired": [], "wanted": os.environ.get("VB_DETERMINISTIC", "1") != "0", "mb": 2048}
 
 
-def set_deterministic(on, workspace_mb=2048, device=None):
+def set_deterministic(on, workspace_mb=None, device=None):
     """Deterministic split-K weight gradients (include/vilbert_hip.h: vb_set_deterministic): the K splits of a launch
     store their partial products to a device workspace and a second kernel adds them in split order - bit-identical
     gradients from run to run, and measured FASTER than the fp32-atomics path (profiles/r03_deterministic_cost.txt), so
-    it is the default (VB_DETERMINISTIC=0 or set_deterministic(False) = atomics). Allocates (once) and registers the
-    workspace (8 per-stream slices of 256 MiB: the largest split launch of the models, the MLM-decoder dgrad at batch 256,
-    needs ~70 MB); returns the previous setting."""
+    it is the default (VB_DETERMINISTIC=0 or set_deterministic(False) = atomics). One workspace PER DEVICE (default
+    2 GiB = 8 per-stream slices of 256 MiB: the largest split launch of the models - a 16-way split of W[3072, 768] -
+    needs ~150 MB), allocated when that device first runs a split launch (`ensure_deterministic`) or here for `device`
+    (default: the current one). A launch that finds no slice (ninth stream of a device) or does not fit falls back to the
+    atomics and is counted (`deterministic_fallbacks()`). Returns the previous setting."""
     import torch
     if on:
-        ws = _DET["workspace"]
-        if ws is None or ws.numel() * 4 < workspace_mb * (1 << 20):
-            ws = torch.empty(workspace_mb * (1 << 20) // 4, dtype=torch.float32, device=device or "cuda")
-        prev = lib().vb_set_deterministic(1, ws.data_ptr(), ws.numel() * 4)
-        if prev < 0:
-            check(prev, "vb_set_deterministic")
-        _DET["workspace"], _DET["wanted"] = ws, True
+        if workspace_mb is not None:
+            _DET["mb"] = int(workspace_mb)
+        prev = _DET["wanted"]
+        _DET["wanted"] = True
+        _register_workspace(torch.device(device or "cuda"))
         return bool(prev)
     prev = lib().vb_set_deterministic(0, None, 0)
-    _DET["workspace"], _DET["wanted"] = None, False
+    _DET["retired"].extend(_DET["ws"].values())
+    _DET["ws"], _DET["wanted"] = {}, False
     return bool(prev)
 
 
+def _register_workspace(device):
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _DET["ws"].get(idx)
+    if ws is None or ws.numel() * 4 < _DET["mb"] * (1 << 20):
+        if ws is not None:
+            _DET["retired"].append(ws)
+        ws = torch.empty(_DET["mb"] * (1 << 20) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+    rc = lib().vb_set_deterministic(1, ws.data_ptr(), ws.numel() * 4)
+    if rc < 0:
+        check(rc, "vb_set_deterministic")
+    _DET["ws"][idx] = ws
+    return ws
+
+
 def ensure_deterministic(device):
-    """Called by the split-K launchers: registers the default workspace on first use (the setting is on by default, the
-    allocation needs the device)."""
-    if _DET["wanted"] and _DET["workspace"] is None:
-        set_deterministic(True, device=device)
+    """Called by the split-K launchers: registers the workspace of `device` on its first split launch (the setting is on
+    by default, the allocation needs the device)."""
+    if _DET["wanted"]:
+        idx = device.index if device.index is not None else current_device()
+        if idx not in _DET["ws"]:
+            _register_workspace(device)
+
+
+def deterministic_workspace(device=None):
+    """The workspace tensor registered for `device` (None if none): GraphedTrainStep holds it while its graph lives."""
+    import torch
+    d = torch.device(device or "cuda")
+    return _DET["ws"].get(d.index if d.index is not None else current_device())
+
+
+def deterministic_fallbacks():
+    """Split launches since the last registration that wanted the ordered reduce but ran with atomics."""
+    return int(lib().vb_deterministic_fallbacks())
 
 
 def set_gemm_v4(mode):

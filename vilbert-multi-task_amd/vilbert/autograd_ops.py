@@ -225,7 +225,7 @@ def _ln_bwd(dy, x, mean, rstd, gamma, beta, need_g, need_b, drop=None):
     res = ops.layernorm_bwd(dy, x, mean, rstd, gamma, c.fresh_or_none(0), c.fresh_or_none(1), drop=drop)
     dx, dgamma, dbeta = res[:3]
     if len(res) == 4:
-        dx._vb_dropped = (drop[0], drop[1], res[3])
+        dx._vb_dropped = (drop[0], drop[1], res[3], dx.data_ptr(), dx._version)
     return dx, (c.finish_overwrite(0, dgamma) if need_g else None), (c.finish_overwrite(1, dbeta) if need_b else None)
 
 
@@ -245,7 +245,11 @@ def _tag_drop(y, drop_p, seed):
 def _dropped(dy, drop):
     """dropout(dy) for the dense node's backward: the twin the LayerNorm kernel already wrote, or a vb_dropout launch."""
     tag = getattr(dy, "_vb_dropped", None)
-    if tag is not None and tag[0] == drop[0] and tag[1] == drop[1] and tag[2].shape == dy.shape:
+    # the twin equals dropout(dy) only while dy still IS the tensor the LayerNorm kernel wrote: same storage and no
+    # in-place write since (autograd's InputBuffer may accumulate a second consumer's gradient in place into a tensor it
+    # holds the only reference to - the Python attribute would survive that, the version counter does not)
+    if (tag is not None and tag[0] == drop[0] and tag[1] == drop[1] and tag[2].shape == dy.shape
+            and tag[3] == dy.data_ptr() and tag[4] == dy._version):
         return tag[2]
     return ops.dropout(dy, drop[0], drop[1])
 
@@ -268,7 +272,7 @@ class LayerNormFn(Function):
         out = dx.view(x.shape)
         tag = getattr(dx, "_vb_dropped", None)
         if tag is not None:
-            out._vb_dropped = (tag[0], tag[1], tag[2].view(x.shape))
+            out._vb_dropped = (tag[0], tag[1], tag[2].view(x.shape), out.data_ptr(), out._version)
         return out, dgamma, dbeta, None
 
 

@@ -97,6 +97,9 @@ class GraphedTrainStep(object):
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._eager_step()
+            # the captured split-K launches store into the deterministic workspace of this device (address and slice baked
+            # into the graph): hold it for as long as the graph can be replayed (_native also retires, never frees, them)
+            self._det_workspace = N.deterministic_workspace(dev)
         finally:
             _A.set_wgrad_stream(prev_ws)
         with torch.no_grad():

@@ -114,3 +114,26 @@ class PreTrainedModel(nn.Module):
             return model, {"missing_keys": missing_keys, "unexpected_keys": unexpected_keys,
                            "error_msgs": error_msgs}
         return model
+
+
+# --- everything else of the reference's vilbert/utils.py (tbLogger :151-482, MultiTaskStopOnPlateau :39-148,
+# cached_path / S3 helpers, ...) is logging / control side and is NOT rebuilt: unknown attributes are looked up in the
+# reference's own utils.py when a reference checkout is attached (vilbert/__init__.py: attach_reference), so
+# `import vilbert.utils as utils; utils.tbLogger(...)` (train_concap.py:29,346-354) keeps working against this package.
+def _reference_utils():
+    try:
+        from . import _reference_utils as ref
+    except ImportError:
+        return None
+    return ref
+
+
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    ref = _reference_utils()
+    if ref is not None and hasattr(ref, name):
+        return getattr(ref, name)
+    raise AttributeError("module 'vilbert.utils' has no attribute %r%s" % (
+        name, "" if ref is not None else " (no reference checkout attached: set VILBERT_REFERENCE_ROOT to use the "
+        "reference's logging / caching helpers)"))
