@@ -147,6 +147,7 @@ def cpu_baseline(cfg, mode, budget_s=25.0):
         times.append(once())
     times.sort()
     med = times[len(times) // 2]
+    all_cores = _cpu_all_cores(mode, B) if (os.cpu_count() or 1) > best_threads else None
     return {"value": round(B / med, 2), "unit": "samples/s", "cores": best_threads, "kind": "port", "batch": B,
             "runs": len(times), "min_median_max_s": [round(times[0], 3), round(med, 3), round(times[-1], 3)],
             "why_port": "the reference source tree (/root/reference) does not exist on the GPU box; the oracle is its "
@@ -156,7 +157,64 @@ def cpu_baseline(cfg, mode, budget_s=25.0):
             "sample": "oracle/vilbert_oracle.py %s, batch %d, median of %d runs (min %.3fs max %.3fs); torch %s "
                       "CPU fp32, %d threads used of %d host cores" %
                       ("fwd+bwd (pre-training losses, autograd)" if train else "forward (VILBertForVLTasks, all heads)",
-                       B, len(times), times[0], times[-1], torch.__version__, best_threads, os.cpu_count())}
+                       B, len(times), times[0], times[-1], torch.__version__, best_threads, os.cpu_count()),
+            "all_cores": all_cores}
+
+
+def _cpu_all_cores(mode, batch, limit_s=40.0):
+    """SURVEY.md section 8(d) asks for `torch.set_num_threads(os.cpu_count())`: the same sample once more with one
+    thread per host core, reported NEXT TO the calibrated figure (on a 256-core host torch's intra-op pool is far
+    slower at these matrix sizes than a few dozen threads). Runs in a child process under a time limit so that the
+    default bench line stays bounded; a run that does not finish reports the limit as an upper bound on its rate."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-sample", mode, "--cpu-threads", str(cores), "--config", CONFIG,
+           "--tokens", str(N_TOK), "--regions", str(N_REG)]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s).stdout
+        rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        return {"value": round(batch / rec["seconds"], 2), "unit": "samples/s", "cores": cores, "batch": batch,
+                "seconds": round(rec["seconds"], 3), "runs": 1}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "samples/s", "cores": cores, "batch": batch, "runs": 0,
+                "note": "one pass did not finish within %.0f s (< %.2f samples/s)" % (limit_s, batch / limit_s)}
+    except Exception as e:           # never let the baseline break the bench line
+        return {"value": None, "cores": cores, "note": "failed after %.1f s: %r" % (time.perf_counter() - t0, e)}
+
+
+def _cpu_sample_main(mode, threads):
+    """Child of _cpu_all_cores: one warm-up + one timed pass of the oracle at `threads` threads; prints {"seconds": s}."""
+    from oracle import synth, vilbert_oracle as vo
+    cfg = json.load(open(os.path.join(ROOT, "vilbert-multi-task_amd", "config", CONFIG)))
+    cfg = dict(synth._DEFAULTS, **cfg)
+    train = mode == "train"
+    B = 16 if train else 64
+    sd = synth.make_state_dict(cfg, "pretraining" if train else "vltasks")
+    x = synth.make_inputs(cfg, B, N_TOK, N_REG + (1 if train else 0), ragged=False, with_labels=train)
+    torch.set_num_threads(threads)
+    if train:
+        args = tuple(x[n] for n in ("input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
+                                    "image_attention_mask", "masked_lm_labels", "image_label", "image_target",
+                                    "next_sentence_label"))
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.predictions.decoder.weight"}
+        leaves["cls.predictions.decoder.weight"] = leaves["bert.embeddings.word_embeddings.weight"]
+
+        def run():
+            for v in leaves.values():
+                v.grad = None
+            sum(l.sum() for l in vo.pretraining_forward(leaves, cfg, *args)).backward()
+    else:
+        args = tuple(x[n] for n in ("input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask",
+                                    "image_attention_mask", "co_attention_mask"))
+
+        def run():
+            with torch.no_grad():
+                vo.vltasks_forward(sd, cfg, *args)
+    run()
+    t0 = time.perf_counter()
+    run()
+    print(json.dumps({"seconds": time.perf_counter() - t0}), flush=True)
 
 
 def main():
@@ -172,6 +230,8 @@ def main():
     ap.add_argument("--tokens", type=int, default=N_TOK, help="tokens per sample (metric: 36)")
     ap.add_argument("--regions", type=int, default=N_REG, help="regions per sample (metric: 36; task shapes: 101)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", choices=["fwd", "train"], default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "bf16x3", "bf16", "fp8"], default="f32",
                     help="GEMM arithmetic: f32 = exact fp32 MFMA (default); bf16x6 = fp32 emulated with 6 bf16 "
                          "MFMA products (fp32-class); bf16x3 = 3 products")
@@ -188,9 +248,16 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the global512 / fwd_b512 legs of the default line")
     ap.add_argument("--deterministic", action="store_true", help="deterministic split-K weight gradients "
                     "(vb_set_deterministic: workspace + ordered reduce instead of atomics; single stream)")
+    ap.add_argument("--ddp-algorithm", choices=["ring", "direct"], default=os.environ.get("VB_DDP_ALGORITHM", "ring"),
+                    help="gradient exchange per bucket at N > 1: ring = one all_reduce, direct = reduce_scatter + "
+                         "all_gather over all xGMI links (vilbert/distributed.py); the N > 1 line times BOTH, this picks "
+                         "the one the headline uses")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even at world size 1 "
                     "(exercises the RCCL bucket path on a single GPU)")
     args = ap.parse_args()
+    if args.cpu_sample:
+        CONFIG, N_TOK, N_REG = args.config, args.tokens, args.regions
+        return _cpu_sample_main(args.cpu_sample, args.cpu_threads or (os.cpu_count() or 1))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,7 +329,7 @@ def main():
             net = build_model(cfg, "pretraining", device).train()
             if world > 1 or args.force_ddp:
                 from vilbert.distributed import DistributedDataParallel
-                net = DistributedDataParallel(net)
+                net = DistributedDataParallel(net, algorithm=args.ddp_algorithm)
             decay = [p for n, p in net.named_parameters() if p.requires_grad and not any(
                 k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
             no_decay = [p for n, p in net.named_parameters() if p.requires_grad and any(
@@ -574,6 +641,23 @@ def main():
     extra = {}
     default_line = args.mode == "train" and CONFIG == "bert_base_6layer_6conect.json" and not args.global_batch \
         and args.batch == 256 and args.gemm_mode == "f32" and not args.no_extra_legs
+    if world > 1 and args.mode == "train" and not args.graph:
+        # the other exchange algorithm on the same model / buckets / batch (the attribute is read per bucket launch)
+        ddp_net = train_state["model"]
+        other = "direct" if ddp_net.algorithm == "ring" else "ring"
+        n_o = max(3, args.steps // 2)
+        ddp_net.algorithm = other
+        try:
+            o_dt = timed(step, 2, n_o)
+        finally:
+            ddp_net.algorithm = args.ddp_algorithm
+        extra["ddp_algorithms"] = {
+            args.ddp_algorithm: {"value": round(B * world * args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                                 "steps": args.steps, "headline": True},
+            other: {"value": round(B * world * n_o / o_dt, 2), "ms_per_step": round(1e3 * o_dt / n_o, 3), "steps": n_o},
+            "unit": "samples/s", "buckets": len(ddp_net._buckets),
+            "note": "same step, gradient buckets exchanged with ring = one all_reduce per bucket vs direct = "
+                    "reduce_scatter_tensor + all_gather_into_tensor in place on the arena range (vilbert/distributed.py)"}
     if default_line and 512 % world == 0:
         gstep, gx, _ = train_workload(512 // world)
         n_g = max(3, args.steps // 2)
@@ -705,7 +789,10 @@ def main():
                          "flops_per_launch_avg": round(gemm_flops / max(gemm_launches, 1), 0)},
         }
         line["config"]["gemm_mode"] = args.gemm_mode
-        line["config"]["deterministic_wgrad"] = bool(args.deterministic)
+        # the STATE, not the flag: ordered split-K is the default (VB_DETERMINISTIC=0 switches to atomics); fallbacks =
+        # split launches that wanted the ordered reduce and ran with atomics (no free workspace slice)
+        line["config"]["deterministic_wgrad"] = bool(_native._DET["wanted"]) and _native.deterministic_workspace(device) is not None
+        line["config"]["deterministic_fallbacks"] = _native.deterministic_fallbacks()
         line.update(extra)
         if alt:
             line["alt_gemm_modes"] = alt

@@ -103,3 +103,81 @@ def test_two_rank_gradient_average_matches_single_process(delay):
                     p -= 0.1 * p.grad
     for n, p in net.named_parameters():
         assert torch.allclose(w0[n], p, atol=1e-5), n
+
+
+# ---- exchange algorithms (round-3 review item 6): "direct" = reduce_scatter + all_gather vs "ring" = all_reduce ---------
+
+def _algo_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "vilbert-multi-task_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vilbert.distributed import DistributedDataParallel as DDP
+    out = {}
+    data = torch.randint(0, 11, (3, 2 * world, 5), generator=torch.Generator().manual_seed(9))
+    for algo, dtype, delay in (("ring", None, False), ("direct", None, False), ("direct", None, True),
+                               ("ring", torch.bfloat16, False), ("direct", torch.bfloat16, False)):
+        torch.manual_seed(5)
+        net = Net()
+        ddp = DDP(net, delay_allreduce=delay, message_size=150, algorithm=algo, bucket_dtype=dtype)
+        assert ddp.algorithm == algo and len(ddp._buckets) > 2
+        assert all(b.flat.numel() % world == 0 for b in ddp._buckets)            # whole shards
+        assert all(v.data_ptr() % 16 == 0 for v in ddp.arena.views)             # kernels' alignment is kept
+        steps = []
+        for step in range(3):
+            ddp.zero_grad()
+            ddp(data[step][rank * 2:(rank + 1) * 2], 0).backward()
+            steps.append({n: p.grad.clone().numpy() for n, p in net.named_parameters() if p.grad is not None})
+            with torch.no_grad():
+                for p in net.parameters():
+                    if p.grad is not None:
+                        p -= 0.1 * p.grad
+        out[(algo, str(dtype), delay)] = steps
+        ddp.arena.release()
+    with pytest.raises(ValueError):
+        DDP(Net(), algorithm="tree")
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_direct_reduce_scatter_all_gather_equals_all_reduce(world):
+    """Same buckets, same gradients: the two-phase exchange must give every rank the SAME averaged gradients as the
+    all-reduce. fp32 addition is commutative, so at world 2 the two are bit-identical; at world 4 the association order
+    of gloo's ring all-reduce and of its reduce-scatter may differ, hence a 1-ulp-scale bound there. bf16 buckets: both
+    algorithms within bf16 rounding of the fp32 result, and identical across ranks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_algo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ring = res[0][("ring", "None", False)]
+    for key in (("direct", "None", False), ("direct", "None", True)):
+        for r in range(world):
+            for step, want in enumerate(ring):
+                got = res[r][key][step]
+                assert got.keys() == want.keys()
+                for n in want:
+                    if world == 2:
+                        assert (got[n] == want[n]).all(), (key, r, step, n)
+                    else:
+                        assert abs(got[n] - want[n]).max() <= 1e-6 * max(1e-3, abs(want[n]).max()), (key, r, step, n)
+    # every rank holds the same values (what data-parallel training needs), whatever the algorithm
+    for key in res[0]:
+        for r in range(1, world):
+            for a, b in zip(res[0][key], res[r][key]):
+                for n in a:
+                    assert (a[n] == b[n]).all(), (key, r, n)
+    for key in (("ring", "torch.bfloat16", False), ("direct", "torch.bfloat16", False)):
+        for step, want in enumerate(ring):
+            for n in want:
+                # steps > 0 start from weights that already differ by the rounding of step 0: compare step 0 tightly
+                if step == 0:
+                    assert abs(res[0][key][0][n] - want[n]).max() <= 2 ** -7 * max(1e-6, abs(want[n]).max()), (key, n)

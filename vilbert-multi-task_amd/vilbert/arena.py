@@ -56,6 +56,7 @@ class GradArena(object):
         if dt != torch.float32:
             raise RuntimeError("GradArena holds fp32 gradients")
         self._cuda = dev.type == "cuda"     # (CPU tensors only in the gloo tests of the data-parallel wrapper)
+        self.align_elems = int(align_elems)
         self.params, self.offsets, self.shapes, seen, total = [], [], [], set(), 0
         for p in params:
             if id(p) in seen:

@@ -24,8 +24,22 @@ Design for MI355X (8 GPUs, 7 xGMI links per GPU, 288 GB HBM each):
     simply extends the wait, one that shows up AFTER its bucket was reduced raises (silently averaging a stale slice
     would corrupt training) - use ``delay_allreduce=True`` (reduce everything after backward, the reference's choice
     for multi-task training) when the used set changes from step to step.
+  * TWO exchange algorithms per bucket (``algorithm=``): ``"ring"`` = one ``all_reduce`` (RCCL picks ring / tree: on
+    the 8-GPU xGMI mesh a ring moves 2 (N-1)/N S bytes over ONE link per GPU, ~153 GB/s); ``"direct"`` = the two-phase
+    form SURVEY.md section 5 / 7.1-8 asks for - ``reduce_scatter_tensor`` of the arena range into this rank's 1/N shard
+    (in place: the shard is a view of the range), then ``all_gather_into_tensor`` of the shards back into the range;
+    with every GPU directly linked to the other seven, each phase sends S/N bytes to each peer over ITS OWN link, i.e.
+    2 S/N per link instead of 2 (N-1)/N S - the arithmetic bench.py's comm_model prices. Both produce the same average
+    (tests/test_distributed_cpu.py compares them bit for bit on gloo); which one is faster on a given node is a
+    measurement (`bench.py --gpus N --ddp-algorithm direct|ring`). Arena slices are padded to a multiple of
+    lcm(4, world) elements so that every bucket divides evenly into shards;
+  * optional reduced-precision exchange (``bucket_dtype=torch.bfloat16``, for the opt-in bf16 / fp8 GEMM modes whose
+    gradients carry ~3 significant digits anyway): the bucket is rounded into a bf16 staging buffer, exchanged at half
+    the bytes, and widened back into the fp32 arena range; master gradients, optimizer state and weights stay fp32.
 Works with any ``torch.distributed`` backend (``nccl`` = RCCL on ROCm; ``gloo`` for the CPU tests).
 """
+import math
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -38,8 +52,10 @@ class _Bucket(object):
         """parameters arena.params[first:last] -> flat[lo:hi]"""
         self.first, self.last = first, last
         self.lo = arena.offsets[first]
-        self.hi = arena.offsets[last - 1] + (arena.params[last - 1].numel() + 3) // 4 * 4
+        al = arena.align_elems
+        self.hi = arena.offsets[last - 1] + (arena.params[last - 1].numel() + al - 1) // al * al
         self.flat = arena.flat[self.lo:self.hi]
+        self.stage = None        # reduced-precision staging copy of the range (bucket_dtype)
         self.expected = None     # set of parameter indices that received a gradient in the previous pass
         self.index = -1          # position in the wrapper's bucket list (launch order = reverse registration order)
         self.reset()
@@ -56,10 +72,20 @@ class DistributedDataParallel(nn.Module):
     constructor subset. ``model.module`` is the wrapped network (the reference checks ``hasattr(model,
     "module")`` when saving, train_concap.py:662-664)."""
 
-    def __init__(self, module, delay_allreduce=False, message_size=16 * 1024 * 1024, process_group=None, **_unused):
+    def __init__(self, module, delay_allreduce=False, message_size=16 * 1024 * 1024, process_group=None,
+                 algorithm=None, bucket_dtype=None, **_unused):
         super(DistributedDataParallel, self).__init__()
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed.init_process_group must be called first")
+        import os
+        algorithm = algorithm or os.environ.get("VB_DDP_ALGORITHM", "ring")
+        if algorithm not in ("ring", "direct"):
+            raise ValueError("algorithm must be 'ring' (one all_reduce per bucket) or 'direct' (reduce_scatter + "
+                             "all_gather), got %r" % (algorithm,))
+        if bucket_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("bucket_dtype must be None / torch.float32 / torch.bfloat16")
+        self.algorithm = algorithm
+        self.bucket_dtype = None if bucket_dtype in (None, torch.float32) else bucket_dtype
         self.module = module
         self.delay_allreduce = delay_allreduce
         self.group = process_group
@@ -77,7 +103,8 @@ class DistributedDataParallel(nn.Module):
                 seen.add(id(p))
                 params.append(p)
         # gradient arena in reverse registration order; the buckets are consecutive runs of it
-        self.arena = GradArena(list(reversed(params)))
+        # (slices padded to lcm(4, world) elements: 16-byte alignment for the kernels, whole shards for "direct")
+        self.arena = GradArena(list(reversed(params)), align_elems=4 * self.world_size // math.gcd(4, self.world_size))
         self._buckets, first, elems = [], 0, 0
         for i, p in enumerate(self.arena.params):
             elems += p.numel()
@@ -155,7 +182,25 @@ class DistributedDataParallel(nn.Module):
             ev.record()
             self.trace.append((b.index, b.flat.numel() * b.flat.element_size(), ev))
         op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
-        b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+        buf = b.flat
+        if self.bucket_dtype is not None:
+            if b.stage is None:
+                b.stage = torch.empty(b.flat.numel(), dtype=self.bucket_dtype, device=b.flat.device)
+            b.stage.copy_(b.flat)                 # round to the exchange precision (one elementwise pass)
+            buf = b.stage
+        if self.algorithm == "ring" or self.world_size == 1:
+            b.work = [dist.all_reduce(buf, op=op, group=self.group, async_op=True)]
+        else:
+            # two-phase exchange, both phases in place: this rank's shard is a view of the range
+            n = buf.numel() // self.world_size
+            r = dist.get_rank(self.group)
+            shard = buf[r * n:(r + 1) * n]
+            rs = dist.reduce_scatter_tensor(shard, buf, op=op, group=self.group, async_op=True)
+            if not self._native_avg:
+                rs.wait()                         # gloo runs asynchronous work on a thread pool: order the phases by hand
+            # (RCCL enqueues both on the process group's stream, in issue order)
+            ag = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
+            b.work = [rs, ag]
         b.launched = True
 
     def arena_backward_done(self):
@@ -172,7 +217,10 @@ class DistributedDataParallel(nn.Module):
             if not b.launched:
                 self._launch(b)
         for b in self._buckets:
-            b.work.wait()
+            for w in b.work:
+                w.wait()
+            if b.stage is not None:
+                b.flat.copy_(b.stage)             # widen the exchanged values back into the fp32 arena range
             if not self._native_avg:
                 b.flat.div_(self.world_size)
             for i in b.ready:
