@@ -117,11 +117,15 @@ def test_gemm_kernels_keep_their_register_budget(native):
                 r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", text, flags=re.S):
             seen += 1
             if "gemm_v4_kernel" in fn:
-                # persistent kernel: 13 waves per CU = 4 on one SIMD -> 128 registers. The dgrad layout with 288 x 128
-                # tiles sits exactly at the budget and keeps three address words in scratch (one reload per two K
-                # steps = per 96 MFMAs, checked in the ISA); anything beyond that is a regression.
-                assert int(vgprs) <= 128, "%s uses %s VGPRs" % (fn, vgprs)
-                assert int(scratch) <= 16, "%s spills %s bytes/lane" % (fn, scratch)
+                # persistent kernel <WM, TM, TM2, TN>. WM = 6: 13 waves per CU = 4 on one SIMD -> 128 registers; the dgrad
+                # layout with 288 x 128 tiles sits exactly at the budget and keeps three address words in scratch (one
+                # reload per two K steps = per 96 MFMAs, checked in the ISA). WM = 4: 9 waves = 3 on one SIMD -> 168
+                # registers; the mixed 320 | 256 x 128 launch (80 accumulator + 72 fragment registers) parks five
+                # accumulators in scratch between the last K step and the epilogue of a tile (5 stores + 5 loads per
+                # output tile, none inside the K loop - checked in the ISA). Anything beyond that is a regression.
+                wm, tm = (int(v) for v in re.search(r"gemm_v4_kernelILi(\d)ELi(\d)E", fn).groups())
+                assert int(vgprs) <= (128 if wm == 6 else 168), "%s uses %s VGPRs" % (fn, vgprs)
+                assert int(scratch) <= (16 if tm < 5 else 96), "%s spills %s bytes/lane" % (fn, scratch)
             else:
                 assert int(scratch) == 0, "%s spills %s bytes/lane" % (fn, scratch)
             if "gemm_f32_kernel" in fn:

@@ -154,3 +154,94 @@ def test_weight_gradient_matches_fp64(ops, v4, M, N, K, nseg):
     v4.set_gemm_v4(2)
     for a, b in zip(dws, dws0):
         assert (a - b).abs().max().item() <= 3e-5 * max(1.0, b.abs().max().item())
+
+
+# ---- round 4: the tile menu of the persistent kernel (wave grid x wave tile as template parameters) ------------------------
+# configuration code WM * 1000 + TM * 100 + TM2 * 10 + TN (plan_v4 in csrc/gemm.hip), forced through the laboratory hook
+# vblab_set_gemm_v4_cfg so that every instantiation is exercised whatever the planner would choose.
+#   4544 / 4543: MIXED 320 | 256-row tiles on 8 MFMA waves - M = 320 a + 256 (32 - a): the image stream at batch 256
+#   (9472 = 20 x 320 + 12 x 256) and the other row counts of that form; N a multiple of 8 column tiles.
+MENU = [(6303, 9216, 768, 64, 1), (6304, 9216, 1024, 64, 1),
+        (4544, 9472, 1024, 64, 1), (4544, 9472, 1024, 96, 3), (4544, 8256, 1024, 64, 1), (4544, 10176, 2048, 32, 1),
+        (4543, 9472, 768, 64, 1), (4543, 9472, 768, 64, 2),
+        (6204, 2304, 1024, 64, 1), (6204, 2368, 1024, 96, 3), (6204, 1000, 128, 32, 1),
+        (6104, 2304, 1024, 64, 1), (6103, 2368, 768, 64, 1), (6103, 2304, 96 * 30, 32, 1),
+        (4202, 2304, 768, 64, 3), (4202, 2368, 1024, 64, 1),
+        (4104, 2304, 3072, 64, 1), (4104, 2368, 1024, 128, 1), (4104, 70, 128, 32, 1)]
+
+
+@pytest.fixture
+def force_cfg():
+    import ctypes
+    from vilbert import _native
+    hook = _native.lib().vblab_set_gemm_v4_cfg
+    hook.restype, hook.argtypes = ctypes.c_int, [ctypes.c_int]
+    hook.last = _native.lib().vblab_last_gemm_v4_cfg
+    hook.last.restype, hook.last.argtypes = ctypes.c_int, []
+    prev_mode = _native.set_gemm_v4(2)
+    yield hook
+    hook(0)
+    _native.set_gemm_v4(prev_mode)
+
+
+@pytest.mark.parametrize("cfg,M,N,K,nseg", MENU)
+def test_menu_configuration_matches_fp64(ops, force_cfg, cfg, M, N, K, nseg):
+    """Forward (bias; GELU + stored derivative; dropout + residual) and dgrad (plain; multiplier; residual gradient) of
+    one configuration against fp64, all rows."""
+    from vilbert import _native
+    force_cfg(cfg)
+    x = _rand(M, K, seed=1)
+    ws = [_rand(N, K, seed=10 + i, scale=0.1) for i in range(nseg)]
+    bs = [_rand(N, seed=20 + i) for i in range(nseg)]
+    dy = _rand(M, nseg * N, seed=3)
+    xd, wd, bd = x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs]
+    pre = torch.cat([x.double() @ w.double().t() + b.double() for w, b in zip(ws, bs)], 1)
+    y, _ = ops.linear_fwd(xd, wd, bd)
+    assert force_cfg.last() == cfg, "the forced configuration did not run"
+    _close(y, pre)
+    if nseg == 1:
+        y, d = ops.linear_fwd(xd, wd, bd, act="gelu", want_act_grad=True)
+        p2 = pre.clone().requires_grad_(True)
+        _gelu64(p2).sum().backward()
+        _close(y, _gelu64(pre))
+        _close(d, p2.grad)
+        r = _rand(M, N, seed=10).cuda()
+        plain, _ = ops.linear_fwd(xd, wd, bd)
+        y, _ = ops.linear_fwd(xd, wd, bd, residual=r, drop_p=0.25, seed=77)
+        want = ops.dropout(plain, 0.25, 77) + r
+        assert (y - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    dyd = dy.cuda()
+    want = dy.double() @ torch.cat(ws, 0).double()
+    tol = 3e-5 * max(1.0, N * nseg / 256)
+    _close(ops.linear_bwd_input(dyd, wd, K), want, 3e-5, tol)
+    # (the dgrad's output width is K: it runs on `cfg` only where K divides into that configuration's columns)
+    assert force_cfg.last() in (cfg, 0)
+    m = _rand(M, K, seed=12)
+    _close(ops.linear_bwd_input(dyd, wd, K, mul=m.cuda()), want * m.double(), 3e-5, tol)
+    _close(ops.linear_bwd_input(dyd, wd, K, residual=m.cuda()), want + m.double(), 3e-5, tol)
+
+
+def test_image_stream_shape_of_the_headline_runs_on_the_mixed_tiles_by_default(ops):
+    """Mode 1 (the default planner): M = 9472 = 37 regions x 256 samples, N = 1024 -> configuration 4544; results equal
+    fp64 on sampled rows. The batch-64 shapes (M = 2304 / 2368) stay on the 4-wave blocks by default (the small-M menu
+    wins isolated A/B runs and loses inside the multi-stream training step: DESIGN.md) - VB_GEMM_V4_SMALLM=1 opts in."""
+    import ctypes
+    from vilbert import _native
+    last = _native.lib().vblab_last_gemm_v4_cfg
+    last.restype, last.argtypes = ctypes.c_int, []
+    assert _native.set_gemm_v4(1) == 1
+    for M, N, K in ((2304, 768, 768), (2368, 1024, 1024)):
+        xs, ws_ = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05)
+        ys, _ = ops.linear_fwd(xs.cuda(), [ws_.cuda()], [None])
+        assert last() == 0, (M, N, K)
+        _close(ys, xs.double() @ ws_.double().t())
+    x, w = _rand(9472, 1024, seed=1), _rand(1024, 1024, seed=2, scale=0.05)
+    xd, wd = x.cuda(), [w.cuda()]
+    y, _ = ops.linear_fwd(xd, wd, [None])
+    assert last() == 4544
+    rows = torch.cat([torch.arange(0, 9472, 97), torch.tensor([6399, 6400, 9471])])      # incl. the 320 | 256 boundary
+    _close(y[rows], x[rows].double() @ w.double().t())
+    _native.set_gemm_v4(0)
+    y0, _ = ops.linear_fwd(xd, wd, [None])
+    _native.set_gemm_v4(1)
+    assert (y - y0).abs().max().item() <= 2e-5 * y.abs().max().item()

@@ -65,7 +65,9 @@ def test_forward_models_train_through_the_hip_model_matches_the_oracle(task_id, 
             assert p.grad is None or p.grad.abs().max().item() <= 2e-7 * gmax, name
             continue
         err = (p.grad.cpu().double() - ref.double()).abs().max().item()
-        bound = 2e-4 * ref.abs().max().item() + 2e-7 * gmax
+        # (+ 5e-7: a gradient that is zero in exact arithmetic - vil_logit.bias under the retrieval cross-entropy, whose
+        # softmax gradients sum to 0 over the options - is pure fp32 rounding noise of an O(1) sum on both sides)
+        bound = 2e-4 * ref.abs().max().item() + 2e-7 * gmax + 5e-7
         assert err <= bound, "%s %s: grad err %.3e > %.3e" % (task_id, name, err, bound)
         seen += 1
     assert seen > 100

@@ -161,8 +161,8 @@ def test_headline_shape_b256_losses_and_every_gradient_match_the_oracle():
         net = net.to(DEV).train()
         decay = [p for n, p in net.named_parameters() if not any(k in n for k in NO_DECAY)]
         no_decay = [p for n, p in net.named_parameters() if any(k in n for k in NO_DECAY)]
-        AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}], lr=LR, betas=BETAS)
-        assert all(A.lookup(p) is not None for p in net.parameters())
+        opt = AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}], lr=LR, betas=BETAS)
+        assert all(A.lookup(p) is not None for p in net.parameters())    # (the arena lives as long as its optimizer)
         lm, img, nsp = net(*helpers.to_device(args, DEV))
         (lm.mean() + img.mean() + nsp.mean()).backward()
         torch.cuda.synchronize()
@@ -186,3 +186,4 @@ def test_headline_shape_b256_losses_and_every_gradient_match_the_oracle():
         assert err <= bound, "B=256 %s: grad err %.3e > %.3e" % (name, err, bound)
         seen += 1
     assert seen > 400
+    assert opt is not None      # keeps the optimizer (and with it the gradient arena) alive up to here

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "../include/vilbert_hip.h"
@@ -228,6 +229,19 @@ int main(int argc, char** argv) {
                                  {Mr, 1024, 1024, 1}, {Mr, 1024, 1024, 3}, {Mr, 1024, 768, 3}, {Mr, 1024, 2048, 1}};
     if (getenv("LAB_LARGE")) shapes = {{Mr, 1024, 1024, 1}, {Mr, 1024, 1024, 3}, {Mr, 4096, 1024, 1}, {Mr, 1024, 4096, 1}};
     if (quick) shapes = {{Mr, 768, 768, 1}, {Mr, 3072, 768, 1}, {Mr, 1024, 1024, 3}};
+    if (const char* e = getenv("LAB_SHAPES")) {       // "N,K,nseg;N,K,nseg;..." at LAB_M rows
+        shapes.clear();
+        std::string str(e);
+        size_t pos = 0;
+        while (pos < str.size()) {
+            size_t end = str.find(';', pos);
+            if (end == std::string::npos) end = str.size();
+            int n = 0, k = 0, sg = 1;
+            if (sscanf(str.substr(pos, end - pos).c_str(), "%d,%d,%d", &n, &k, &sg) >= 2) shapes.push_back({Mr, n, k, sg});
+            pos = end + 1;
+        }
+    }
+    const bool no_wgrad = getenv("LAB_NOWGRAD") != nullptr;
     printf("VB_GEMM_V2=%s VB_GEMM_TILE=%s VB_GEMM_ABL=%s M=%d\n", getenv("VB_GEMM_V2") ? getenv("VB_GEMM_V2") : "-",
            getenv("VB_GEMM_TILE") ? getenv("VB_GEMM_TILE") : "-", getenv("VB_GEMM_ABL") ? getenv("VB_GEMM_ABL") : "-", Mr);
     double tot_f = 0, tot_t = 0;
@@ -274,6 +288,7 @@ int main(int argc, char** argv) {
         timeline("dgrad", [&] { vb_linear_bwd_input(nullptr, &g); });
         v4_ab("dgrad", fl, [&] { vb_linear_bwd_input(nullptr, &g); });
         tot_f += fl; tot_t += us;
+        if (no_wgrad) { for (float* p : {x, w, b, y, dy, dx, dw, db}) CK(hipFree(p)); continue; }
         // wgrad: dw[N,K] = dy^T . x (+ bias gradient)
         vb_linear_bwd_weight_args wg;
         memset(&wg, 0, sizeof(wg));

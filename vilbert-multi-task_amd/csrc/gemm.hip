@@ -286,7 +286,7 @@ int gemm_tile_code() {
 // Cost model: a CU retires "16 x 16 tile K-steps" at a fixed rate once its matrix pipes are saturated, the blocks of
 // a launch are dealt round-robin, so the launch takes ceil(blocks / 256) blocks of TM TN (K steps + overhead) tile
 // steps on the busiest CU; eff = measured relative main-loop efficiency of the tile shape (tools/gemm_lab).
-struct V2Plan { int tm1, tm2, tn, big_rows, small_rows, tiles_n, splits, kt_per_split; };
+struct V2Plan { int tm1, tm2, tn, big_rows, small_rows, tiles_n, splits, kt_per_split; double cost; };
 
 bool aligned_ld(const void* ptr, long ld) { return ptr == nullptr || (vb_aligned16(ptr) && ld % 4 == 0); }
 
@@ -384,7 +384,7 @@ bool plan_v2(const GemmP& p, bool vec, int splits, V2Plan& best) {
                 const double cost = v2_launch_cost(n1 * sp, tm1 * tn, n2 * sp, tm2 * tn, steps, occ) / eff(tm2, tn);
                 if (cost < best_cost - 1e-9) {
                     best_cost = cost;
-                    best = {tm1, tm2, tn, nb, ns, tiles_n, sp, per};
+                    best = {tm1, tm2, tn, nb, ns, tiles_n, sp, per, cost};
                 }
             }
         }
@@ -608,27 +608,91 @@ int launch_wgrad_skinny(hipStream_t st, const vb_linear_bwd_weight_args* a) {
     return 0;
 }
 
-int plan_v4(const GemmP& p, bool b_kc) {
+// -> configuration code WM * 1000 + TM * 100 + TM2 * 10 + TN of the persistent kernel (gemm_v4.h, dispatch_v4 in
+// gemm_v2.hip), 0 = not used. Round 4: a tile menu instead of the two 288-row shapes -
+//   * the round-3 shapes 288 x 128 / 288 x 96 (12 MFMA waves);
+//   * MIXED 320 | 256-row tiles on 8 MFMA waves when M = 320 a + 256 (32 - a): the 37-region image stream at batch 256
+//     (M = 9472 = 20 x 320 + 12 x 256) becomes exactly 32 row tiles x N / 128 column tiles - one tile per CU and round;
+//   * small-M shapes (per-GPU batch 64: M = 2304 / 2368 rows - 64 tiles of 288 rows would leave 192 CUs idle): 192 x 128,
+//     96 x 128, 96 x 96 (12 waves), 128 x 64, 64 x 128 (8 waves).
+// Choice by a TIME model fitted to in-process A/B runs of every configuration on the model's shapes
+// (tools/lab_v4_menu.sh, profiles/r04_gemm_lab_v4_menu_*.txt): a persistent launch costs
+//     9.4 us  +  rounds x K steps x (ideal matrix-pipe time of one tile K step) / 0.94  +  (rounds - 1) x 12 us
+// (launch + prologue + epilogue are ~9.4 us whatever the tile; every configuration's K step runs at ~0.94 of the pipe;
+// an output-tile boundary inside a launch is a store burst), with the mixed launch timed by its 320-row
+// tiles; the 4-wave alternative costs 0.93 x (plan_v2's modelled cost, in 32 x 32-tile K steps of 53.4 ns). The persistent
+// kernel is taken when its modelled time is lower (mode 1), always when eligible (mode 2).
+// VB_GEMM_V4_CFG=<code> / vblab_set_gemm_v4_cfg force one configuration wherever the shape allows it (laboratory, tests).
+struct V4Opt { int wm, tm, tn; };
+int g_v4_force_cfg = -1;
+int g_v4_last_cfg = 0;
+int plan_v4(const GemmP& p, bool b_kc, double v2_cost) {
     const int mode = gemm_v4_mode();
     if (mode == 0) return 0;
     if (p.K % 32 != 0 || p.C[1] != nullptr || p.epi == EPI_ATOMIC || p.epi == EPI_GENERIC || p.epi == EPI_PRE_GELU) return 0;
     static const int force_tn = [] { const char* e = getenv("VB_GEMM_V4_TN"); return e ? atoi(e) : 0; }();
-    const int rows = (p.M + 287) / 288;
-    double best = 0.0;
-    int best_tn = 0;
-    long best_tiles = 0;
-    for (int tn = 4; tn >= 3; --tn) {          // ties go to the wider tile (fewer operand bytes per flop)
-        if (p.N % (32 * tn) != 0 || (force_tn != 0 && force_tn != tn)) continue;
-        if (b_kc && p.B[1] != nullptr && p.bseg % (32 * tn) != 0) continue;   // a tile must not straddle two stacked weights
-        const long tiles = (long)rows * (p.N / (32 * tn));
-        // useful fraction of the launch: whole rounds of 256 blocks, the rows past M of the last row tile are wasted
-        const double eff = (double)tiles / (double)((tiles + 255) / 256 * 256) * ((double)p.M / (rows * 288.0));
-        if (eff > best + 1e-9) { best = eff; best_tn = tn; best_tiles = tiles; }
+    if (g_v4_force_cfg < 0) { const char* e = getenv("VB_GEMM_V4_CFG"); g_v4_force_cfg = e ? atoi(e) : 0; }
+    const int force_cfg = g_v4_force_cfg;
+    static const double margin = [] { const char* e = getenv("VB_GEMM_V4_MARGIN"); return e ? atof(e) : 0.98; }();
+    auto cols_ok = [&](int tn) {
+        if (p.N % (32 * tn) != 0) return false;
+        return !(b_kc && p.B[1] != nullptr && p.bseg % (32 * tn) != 0);   // a tile must not straddle two stacked weights
+    };
+    constexpr double CU_FLOPS = 157.3e12 / 256.0, T_FIXED = 9.4e-6, T_BOUNDARY = 12e-6, STEP_EFF = 0.94;
+    const double nk = p.K / 16;
+    auto model = [&](int bm, int bn, long tiles) {
+        const double rounds = (double)((tiles + 255) / 256);
+        return T_FIXED + rounds * nk * (2.0 * bm * bn * 16.0 / CU_FLOPS) / STEP_EFF + (rounds - 1.0) * T_BOUNDARY;
+    };
+    static const V4Opt menu[] = {{6, 3, 4}, {6, 3, 3}, {6, 2, 4}, {6, 1, 4}, {6, 1, 3}, {4, 2, 2}, {4, 1, 4}};
+    // VB_GEMM_V4_MENU=0: the round-3 planner (288-row shapes only, >= 0.90 fill) for A/B runs
+    static const bool menu_on = [] { const char* e = getenv("VB_GEMM_V4_MENU"); return e == nullptr || atoi(e) != 0; }();
+    double best = 1e30;
+    int best_cfg = 0;
+    bool best_fills = false;
+    for (const V4Opt& o : menu) {
+        if (!cols_ok(o.tn) || (force_tn != 0 && force_tn != o.tn)) continue;
+        const int cfg = o.wm * 1000 + o.tm * 100 + o.tn;
+        if (force_cfg != 0 && force_cfg != cfg) continue;
+        if (!menu_on && o.tm != 3) continue;
+        const int bm = 16 * o.tm * o.wm;
+        const long rows = (p.M + bm - 1) / bm, tiles = rows * (p.N / (32 * o.tn));
+        const double t = model(bm, 32 * o.tn, tiles);
+        if (t < best - 1e-12) {
+            best = t;
+            best_cfg = cfg;
+            // the round-3 rule: a 288-row shape whose launched tile slots are >= 90 % useful
+            best_fills = o.tm == 3 && (double)tiles / (double)((tiles + 255) / 256 * 256) * ((double)p.M / (rows * 288.0)) >= 0.90;
+        }
     }
-    if (best_tn == 0) return 0;
-    if (mode == 2) return best_tn;
-    (void)best_tiles;
-    return best >= 0.90 ? best_tn : 0;
+    bool best_mixed = false;
+    // mixed 320 | 256-row tiles (8 MFMA waves): M = 320 a + 256 (32 - a), 0 < a < 32
+    for (int tn = 4; tn >= 3 && menu_on; --tn) {
+        const int cfg = 4540 + tn;
+        if (!cols_ok(tn) || (p.N / (32 * tn)) % 8 != 0 || (force_cfg != 0 && force_cfg != cfg) || (force_tn != 0 && force_tn != tn)) continue;
+        const int rest = p.M - 32 * 256;
+        if (rest <= 0 || rest % 64 != 0 || rest / 64 >= 32) continue;
+        const double t = model(320, 32 * tn, 32L * (p.N / (32 * tn)));
+        if (t < best - 1e-12) { best = t; best_cfg = cfg; best_mixed = true; best_fills = false; }
+    }
+    if (best_cfg == 0) return 0;
+    if (mode == 2 || force_cfg != 0) return best_cfg;
+    // mode 1. Measured (in-process A/B on every shape of the model, profiles/r03_gemm_lab_v4_ab_*.txt,
+    // r04_gemm_lab_v4_menu_*.txt): the 288-row shapes that fill the chip and the mixed launch beat the 4-wave blocks on
+    // every forward / dgrad shape (+3 ... +13 %). For the small-M menu the two models are compared; plan_v2's cost is in
+    // 32 x 32-tile K steps (53.4 ns on a saturated CU) and tracks the measured time (x 0.93) while a CU holds at most two
+    // 4-wave blocks - beyond that (large M, where the menu has nothing to offer anyway) it is not calibrated: 4-wave.
+    if (best_fills || best_mixed) return best_cfg;
+    // The small-M menu wins every isolated A/B (+8 ... +19 % at M = 2304 / 2368) and LOSES inside the batch-64 training step
+    // (1,866 vs 1,954 samples/s, profiles/r04_bench_b64_menu_ab.txt): there the text / image / weight-gradient streams keep
+    // several kernels in flight, the 4-wave blocks of different kernels co-reside on a CU and cover each other's bubbles,
+    // while a persistent block owns its CU - so it is opt-in (VB_GEMM_V4_SMALLM=1: single-stream inference, laboratory).
+    static const bool small_m = [] { const char* e = getenv("VB_GEMM_V4_SMALLM"); return e != nullptr && atoi(e) != 0; }();
+    if (!menu_on || !small_m) return 0;
+    const long v2_tiles = (long)((p.M + 95) / 96) * ((p.N + 95) / 96);     // upper bound of plan_v2's block count
+    if (v2_tiles > 3 * 256) return 0;
+    const double t_v2 = 0.93 * 53.4e-9 * v2_cost;
+    return best < margin * t_v2 ? best_cfg : 0;
 }
 
 // Persistent weight-gradient kernel (gemm_v4w.h): 384 x 96 tiles of dW times K splits as equal work units. Fills the
@@ -694,8 +758,9 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
         }
         // persistent 288-row tiles (gemm_v4.h) where they fill the chip in whole rounds
         if (A_KC && splits == 1) {
-            const int tn4 = plan_v4(p, B_KC);
-            if (tn4 != 0) return B_KC ? launch_gemm_v4_nt(st, p, tn4) : launch_gemm_v4_nn(st, p, tn4);
+            const int cfg4 = plan_v4(p, B_KC, pl.cost);
+            g_v4_last_cfg = cfg4;
+            if (cfg4 != 0) return B_KC ? launch_gemm_v4_nt(st, p, cfg4) : launch_gemm_v4_nn(st, p, cfg4);
         }
         p.tiles_n = pl.tiles_n;
         p.ktiles_per_split = pl.kt_per_split;
@@ -767,6 +832,15 @@ int launch_gemm(hipStream_t st, GemmP p, bool vec, int splits, int legacy_splits
 // Laboratory hook (tools/gemm_lab.cpp, not part of the product ABI): device buffer of 2 x uint64 receiving
 // {shader cycles of the K loop of block 128, its K steps} of every following second-generation GEMM launch.
 extern "C" void vblab_gemm_cycles(unsigned long long* dev_buf) { g_dbg = dev_buf; }
+// Laboratory / test hook (not part of the product ABI): force one persistent-kernel configuration (plan_v4 code, 0 = the
+// planner's choice) wherever the shape allows it. Returns the previous value.
+// configuration code of the most recent forward / dgrad launch that reached the planner (0 = it ran on the 4-wave blocks)
+extern "C" int vblab_last_gemm_v4_cfg(void) { return g_v4_last_cfg; }
+extern "C" int vblab_set_gemm_v4_cfg(int cfg) {
+    const int prev = g_v4_force_cfg < 0 ? 0 : g_v4_force_cfg;
+    g_v4_force_cfg = cfg;
+    return prev;
+}
 
 extern "C" int vb_set_gemm_tile(int code) {
     const int prev = gemm_tile_code();

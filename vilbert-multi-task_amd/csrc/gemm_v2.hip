@@ -5,6 +5,9 @@
 // Each object instantiates the tile menu {64x64, 96x96, 96x128, 128x96, 128x128} (block tile = 32 TM x 32 TN) and the
 // mixed-height launches {128 | 96} x {128, 96}, {96 | 64} x {128, 96}.
 #include "gemm_v4w.h"
+#ifdef VB_GEMM_LAB
+#include "gemm_v3.h"      // the rejected 5-wave design: laboratory build only
+#endif
 
 #ifndef VB_V2_LAYOUT
 #error "compile with -DVB_V2_LAYOUT=0|1|2"
@@ -87,25 +90,62 @@ int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
 }
 
 #if VB_V2_LAYOUT != 2
-// persistent one-block-per-CU kernel (gemm_v4.h): 288 x 96 (TN = 3) / 288 x 128 (TN = 4) tiles
-template <int TN>
-__global__ __launch_bounds__(V4_THREADS, 4) void gemm_v4_kernel(const GemmP p) {
+// persistent one-block-per-CU kernel (gemm_v4.h). TM2 != 0: two tile heights in one launch (blocks whose row tile is one of
+// the first p.n_small run TM, the others TM2 - a block-uniform branch; registers and LDS are those of the taller tile)
+template <int WM, int TM, int TM2, int TN>
+__global__ __launch_bounds__((V4Cfg<WM, TM, TN, B_KC>::THREADS), (WM == 6 ? 4 : 3)) void gemm_v4_kernel(const GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_block_v4<3, TN, B_KC>(p, smem);
+    if (TM2 == 0) {
+        gemm_block_v4<WM, TM, TN, B_KC, false>(p, smem);
+    } else {
+        const int r = 4 * (blockIdx.x & 7) + (blockIdx.x >> 6);
+        if (r < p.n_small) gemm_block_v4<WM, TM, TN, B_KC, true>(p, smem);
+        else gemm_block_v4<WM, (TM2 == 0 ? TM : TM2), TN, B_KC, true>(p, smem);
+    }
 }
 
-template <int TN>
+template <int WM, int TM, int TM2, int TN>
 int launch_v4(hipStream_t st, GemmP p) {
-    using Cfg = V4Cfg<3, TN, B_KC>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<TN>),
+    using Cfg = V4Cfg<WM, TM, TN, B_KC>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v4_kernel<WM, TM, TM2, TN>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (attr != hipSuccess) return (int)attr;
+    // laboratory: VB_GEMM_V4_EXCL=0 lets the small-tile configurations share a CU with another block (no LDS padding)
+    static const bool excl = [] { const char* e = getenv("VB_GEMM_V4_EXCL"); return e == nullptr || atoi(e) != 0; }();
+    const int lds_bytes = excl ? Cfg::LDS_BYTES : Cfg::RING_BYTES;
     p.tiles_n = p.N / Cfg::BN;
-    p.n_big = ((p.M + Cfg::BM - 1) / Cfg::BM) * p.tiles_n;
-    const int grid = p.n_big < 256 ? p.n_big : 256;
-    hipLaunchKernelGGL((gemm_v4_kernel<TN>), dim3(grid), dim3(V4_THREADS), Cfg::LDS_BYTES, st, p);
+    int grid;
+    if (TM2 != 0) {
+        // 32 row tiles: n_tall of 16 TM WM rows, the rest of 16 TM2 WM rows, covering M exactly (checked by plan_v4)
+        constexpr int H1 = Cfg::BM, H2 = 16 * TM2 * WM;
+        const int n_tall = (p.M - 32 * H2) / (H1 - H2);
+        p.n_small = n_tall;
+        p.m_split = n_tall * H1;
+        p.n_big = 32 * p.tiles_n;
+        grid = 256;
+    } else {
+        p.n_big = ((p.M + Cfg::BM - 1) / Cfg::BM) * p.tiles_n;
+        grid = p.n_big < 256 ? p.n_big : 256;
+    }
+    hipLaunchKernelGGL((gemm_v4_kernel<WM, TM, TM2, TN>), dim3(grid), dim3(Cfg::THREADS), lds_bytes, st, p);
     VB_LAUNCH_CHECK();
     return 0;
+}
+
+// cfg = WM * 1000 + TM * 100 + TM2 * 10 + TN (plan_v4 in gemm.hip)
+int dispatch_v4(hipStream_t st, const GemmP& p, int cfg) {
+    switch (cfg) {
+        case 6303: return launch_v4<6, 3, 0, 3>(st, p);
+        case 6304: return launch_v4<6, 3, 0, 4>(st, p);
+        case 4544: return launch_v4<4, 5, 4, 4>(st, p);     // 320 | 256 x 128 mixed: M = 9472
+        case 4543: return launch_v4<4, 5, 4, 3>(st, p);
+        case 6204: return launch_v4<6, 2, 0, 4>(st, p);     // 192 x 128
+        case 6103: return launch_v4<6, 1, 0, 3>(st, p);     // 96 x 96
+        case 6104: return launch_v4<6, 1, 0, 4>(st, p);     // 96 x 128
+        case 4202: return launch_v4<4, 2, 0, 2>(st, p);     // 128 x 64
+        case 4104: return launch_v4<4, 1, 0, 4>(st, p);     // 64 x 128
+        default: return VB_E_BADARG;
+    }
 }
 #endif
 
@@ -156,9 +196,9 @@ int launch_gemm_v4_tn(hipStream_t st, const GemmP& p, int cfg) {
 }
 #endif
 #if VB_V2_LAYOUT == 0
-int launch_gemm_v4_nt(hipStream_t st, const GemmP& p, int tn) { return tn == 3 ? launch_v4<3>(st, p) : launch_v4<4>(st, p); }
+int launch_gemm_v4_nt(hipStream_t st, const GemmP& p, int cfg) { return dispatch_v4(st, p, cfg); }
 #elif VB_V2_LAYOUT == 1
-int launch_gemm_v4_nn(hipStream_t st, const GemmP& p, int tn) { return tn == 3 ? launch_v4<3>(st, p) : launch_v4<4>(st, p); }
+int launch_gemm_v4_nn(hipStream_t st, const GemmP& p, int cfg) { return dispatch_v4(st, p, cfg); }
 #endif
 #if VB_V2_LAYOUT == 0
 int launch_gemm_v2_nt(hipStream_t st, const GemmP& p, int tm1, int tm2, int tn, int tiles, int splits) { return dispatch(st, p, tm1, tm2, tn, tiles, splits); }

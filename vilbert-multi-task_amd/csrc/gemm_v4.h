@@ -1,6 +1,6 @@
 // Fourth-generation fp32 GEMM: ONE persistent, wave-specialised block per compute unit.
 //
-//   block  = 13 waves: 12 MFMA waves in a 6 x 2 grid (3 per SIMD) + 1 loader wave (LDS-DMA only, gemm_v3.h)
+//   block  = 13 waves: 12 MFMA waves in a 6 x 2 grid (3 per SIMD) + 1 loader wave (LDS-DMA only)
 //   tile   = (6 . 16 TM) x (2 . 16 TN) = 288 x 96 (TM = TN = 3) or 288 x 128 (TN = 4): the batch-256 text stream has
 //            M = 9216 = 32 x 288 rows, so N = 768 / 1024 give exactly 256 tiles (one per CU) and N = 2304 / 3072 exactly
 //            768 (three per CU, run back to back by the same block)
@@ -20,24 +20,39 @@
 // Layouts: forward (NT) and dgrad (NN); the A operand is always k-contiguous. No split-K (launches that need it stay
 // on gemm_v2.h). Requires K % 32 == 0 (an even number of K steps per tile keeps the fragment-set parity static).
 #pragma once
-#include "gemm_v3.h"
+#include "gemm_v2.h"
 
 namespace vbgemm {
 
-constexpr int V4_WM = 6, V4_WN = 2, V4_MFMA_WAVES = V4_WM * V4_WN, V4_THREADS = 64 * (V4_MFMA_WAVES + 1);
+// Round 4: the kernel is a template over the wave grid and the wave tile - WM x 2 MFMA waves (WM = 6: 12 waves, three per
+// SIMD, 128 registers; WM = 4: 8 waves, two per SIMD, 168 registers) of (16 TM) x (16 TN) outputs each, + the loader
+// wave. Block tile = (16 TM WM) x (32 TN):
+//   WM = 6, TM = 3: 288 x 96 / 288 x 128   the round-3 kernel (M = 9216, 18432: batch-256 / 512 text stream, bert_large)
+//   WM = 4, TM = 5 | 4 MIXED in one launch: 20 row tiles of 320 rows + 12 of 256 rows = 9472 rows = the 37-region image
+//           stream at batch 256 (M = 2^8 x 37 has no equal tiling into <= 256 tiles of 16-row fragments on a wave grid whose
+//           wave count is a multiple of 4; 32 row tiles x 8 column tiles of 128 = exactly 256 tiles, one per CU, 0.925 of
+//           the tallest tile's time useful)
+//   small-M menu (the per-GPU batch 64 of BASELINE configs[2]: M = 2304 / 2368): WM = 4 / 6 with TM = 1, 2 - see plan_v4
 constexpr int V4_STAGES = 4;
+constexpr int V4_WN = 2;            // wave columns of every persistent configuration
 
-template <int TM, int TN, bool B_KC>
+template <int N>
+__device__ __forceinline__ void v4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int TM, int TN, bool B_KC>
 struct V4Cfg {
-    static constexpr int BM = 16 * TM * V4_WM, BN = 16 * TN * V4_WN;
+    static constexpr int MFMA_WAVES = WM * 2, THREADS = 64 * (MFMA_WAVES + 1);
+    static constexpr int BM = 16 * TM * WM, BN = 16 * TN * 2;
     static constexpr int A_SZ = BM * 16;                              // k-contiguous [rows][16], slot-swizzled
     static constexpr int B_SZ = B_KC ? BN * 16 : 16 * (BN + 4);       // or row-contiguous [16 k][cols + 4]
     static constexpr int STAGE = A_SZ + B_SZ;
-    static constexpr int LDS_BYTES = V4_STAGES * STAGE * 4;
+    static constexpr int RING_BYTES = V4_STAGES * STAGE * 4;
+    // exactly one block per CU is part of the design: small tiles ask for more LDS than they use
+    static constexpr int LDS_BYTES = RING_BYTES > 82 * 1024 ? RING_BYTES : 82 * 1024;
     static constexpr int A_SLOTS = A_SZ / 4, B_SLOTS = B_SZ / 4;
     static constexpr int NA = (A_SLOTS + 63) / 64, NB = (B_SLOTS + 63) / 64, NI = NA + NB;
     static_assert(2 * NI <= 63, "vmcnt is a 6-bit counter");
-    static_assert(2 * LDS_BYTES > 160 * 1024, "exactly one block per CU is part of the design");
+    static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the CU");
 };
 
 // tile of block `b` in round `it` of a persistent launch over `tiles` output tiles on `grid` blocks: the blocks of one
@@ -62,7 +77,7 @@ __device__ __forceinline__ void v4_glds16(unsigned off, const float* base, unsig
 
 // (row, column) of output tile `t`. The 32 tiles an XCD works on at any time (v4_tile_of) should share as few A / W
 // panels as possible: where the tile grid allows it they form a 4 x 8 patch (4 A panels + 8 W panels per XCD and round
-// instead of 1.3 + 24 for a 24-column grid walked row by row: measured 7.0x -> see profiles/r03_gemm_pmc_table.txt for
+// instead of 1.3 + 24 for a 24-column grid walked row by row: measured 7.0x -> see profiles/r03_gemm_pmc.txt for
 // the operand bytes fetched through the fabric per launch); other grids are walked row by row (N fastest).
 __device__ __forceinline__ void v4_tile_rc(int t, int tiles, int tiles_n, int& r, int& c) {
     const int tiles_m = tiles / tiles_n;
@@ -76,10 +91,35 @@ __device__ __forceinline__ void v4_tile_rc(int t, int tiles, int tiles_n, int& r
     }
 }
 
-template <int TM, int TN, bool B_KC>
+// first row / column of the output tile block `b` works on in round `it`; false = no tile (the block is done).
+// MIXED (two tile heights in one launch; p.n_small = number of TALL row tiles, p.m_split = the rows they cover, 32 row tiles
+// in all, tiles_n a multiple of 8): block b = XCD x (b & 7), slot j (b >> 3); the XCD owns row tiles 4x .. 4x + 3, the slot
+// picks one of them (j >> 3) and a column (j & 7) inside the round's group of 8 columns - so a block keeps its row tile (and
+// with it its height class and its A panel) across the rounds, and an XCD works on a 4 x 8 patch as in the uniform map.
+// BM is the CALLER's tile height: tall blocks only ever see tall row tiles, short blocks short ones.
+template <int BM, int BN, bool MIXED>
+__device__ __forceinline__ bool v4_origin(const GemmP& p, int b, int it, int grid, int tiles, int& m0, int& n0) {
+    if (MIXED) {
+        const int x = b & 7, j = b >> 3;
+        const int r = 4 * x + (j >> 3), c = it * 8 + (j & 7);
+        if (c >= p.tiles_n) return false;
+        m0 = r < p.n_small ? r * BM : p.m_split + (r - p.n_small) * BM;
+        n0 = c * BN;
+        return true;
+    }
+    const int t = v4_tile_of(b, it, grid, tiles);
+    if (t < 0) return false;
+    int tr, tc;
+    v4_tile_rc(t, tiles, p.tiles_n, tr, tc);
+    m0 = tr * BM;
+    n0 = tc * BN;
+    return true;
+}
+
+template <int WM, int TM, int TN, bool B_KC, bool MIXED>
 __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, const int lane, const int nk,
                                           const int tiles, const int rounds) {
-    using Cfg = V4Cfg<TM, TN, B_KC>;
+    using Cfg = V4Cfg<WM, TM, TN, B_KC>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NA = Cfg::NA, NB = Cfg::NB, NI = Cfg::NI, S = V4_STAGES;
     unsigned oa[NA], ob[NB];          // per-lane byte offsets from the tile's scalar bases (constant per output tile)
     bool okb[NB];
@@ -87,10 +127,9 @@ __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, c
     const float* bbase = nullptr;     // k-contiguous B: W_seg + n_local0 * ldb + k; row-contiguous B: W_seg + k_local * ldb + n0
     int b_seg = 0, b_krem = 0, n0_cur = 0;
     // source addressing of one output tile (A rows clamped to the matrix: rows past M are computed but never stored)
-    auto set_tile = [&](int tile) {
-        int tr, tc;
-        v4_tile_rc(tile, tiles, p.tiles_n, tr, tc);
-        const int m0 = tr * BM, n0 = tc * BN;
+    auto set_tile = [&](int round) {
+        int m0 = 0, n0 = 0;
+        v4_origin<BM, BN, MIXED>(p, blockIdx.x, round, gridDim.x, tiles, m0, n0);
         abase = p.A + (long)m0 * p.lda;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -124,7 +163,6 @@ __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, c
         }
     };
     int it = 0, kt = 0, stage_w = 0;   // next K tile to issue: (round, kt), into stage stage_w
-    const int b = blockIdx.x;
     auto issue_next = [&]() {
         const unsigned la = lds0 + (unsigned)stage_w * (Cfg::STAGE * 4);
         const unsigned lb = la + Cfg::A_SZ * 4;
@@ -147,16 +185,16 @@ __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, c
         if (++kt == nk) {
             kt = 0;
             ++it;
-            if (it < rounds) set_tile(v4_tile_of(b, it, gridDim.x, tiles));
+            if (it < rounds) set_tile(it);
         }
     };
     auto wait_pending = [&](int k_tiles) {   // at most k_tiles of the most recently issued K tiles still in flight
-        if (k_tiles >= 2) v3_wait_vm<2 * NI>();
-        else if (k_tiles == 1) v3_wait_vm<NI>();
-        else v3_wait_vm<0>();
+        if (k_tiles >= 2) v4_wait_vm<2 * NI>();
+        else if (k_tiles == 1) v4_wait_vm<NI>();
+        else v4_wait_vm<0>();
     };
     const int total = rounds * nk;           // K tiles of this block's stream
-    set_tile(v4_tile_of(b, 0, gridDim.x, tiles));
+    set_tile(0);
     __builtin_amdgcn_s_setprio(2);
     for (int s = 0; s < S && s < total; ++s) issue_next();
     wait_pending(min(total, S) - 2);         // K tiles 0, 1 have landed
@@ -194,16 +232,17 @@ __device__ __forceinline__ void v4_loader(const GemmP& p, const unsigned lds0, c
 #endif
 }
 
-template <int TM, int TN, bool B_KC>
+template <int WM, int TM, int TN, bool B_KC, bool MIXED>
 __device__ __forceinline__ void gemm_block_v4(const GemmP& p, float* __restrict__ smem) {
-    using Cfg = V4Cfg<TM, TN, B_KC>;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, S = V4_STAGES;
+    using Cfg = V4Cfg<WM, TM, TN, B_KC>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, S = V4_STAGES, V4_MFMA_WAVES = Cfg::MFMA_WAVES;
     const int tiles = p.n_big;               // output tiles of the launch
     const int nk = p.K / V2_BK;              // even (K % 32 == 0)
     const int b = blockIdx.x, grid = gridDim.x;
     // rounds this block takes part in (a block whose tile index falls off the end of the last round stops earlier)
     int rounds = 0;
-    while (rounds * grid < tiles && v4_tile_of(b, rounds, grid, tiles) >= 0) ++rounds;
+    if (MIXED) rounds = p.tiles_n >> 3;
+    else while (rounds * grid < tiles && v4_tile_of(b, rounds, grid, tiles) >= 0) ++rounds;
     if (rounds == 0) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef VB_GEMM_LAB
@@ -212,7 +251,7 @@ __device__ __forceinline__ void gemm_block_v4(const GemmP& p, float* __restrict_
 #endif
     if (wave == V4_MFMA_WAVES) {
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-        v4_loader<TM, TN, B_KC>(p, __builtin_amdgcn_readfirstlane(lds0), threadIdx.x & 63, nk, tiles, rounds);
+        v4_loader<WM, TM, TN, B_KC, MIXED>(p, __builtin_amdgcn_readfirstlane(lds0), threadIdx.x & 63, nk, tiles, rounds);
         return;
     }
     f32x4 acc[TM][TN], afr[2][TM], bfr[2][TN];
@@ -303,6 +342,7 @@ __device__ __forceinline__ void gemm_block_v4(const GemmP& p, float* __restrict_
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const bool last_round = it + 1 == rounds;
+        (void)last_round;
         if (it > 0) {
             // fragments of this tile's first K tile (its stage landed before the previous barrier). Read here and not
             // under the last MFMAs of the previous tile, so that no fragment register is live across the epilogue.
@@ -330,9 +370,8 @@ __device__ __forceinline__ void gemm_block_v4(const GemmP& p, float* __restrict_
         asm volatile("v_mov_b32 %0, %1" : "=v"(tid2) : "v"(threadIdx.x));
         const int lane = tid2 & 63, l15 = lane & 15, g = lane >> 4, w2 = tid2 >> 6;
         const int wm = w2 >> 1, wn = w2 & 1;
-        int tr, tc;
-        v4_tile_rc(v4_tile_of(b, it, grid, tiles), tiles, p.tiles_n, tr, tc);
-        const int m0 = tr * BM, n0 = tc * BN;
+        int m0 = 0, n0 = 0;
+        v4_origin<BM, BN, MIXED>(p, b, it, grid, tiles, m0, n0);
         const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
         float* cbase = p.C[0];
         const int row0 = m0 + wm * 16 * TM + l15, col0 = n0 + wn * 16 * TN + 4 * g;

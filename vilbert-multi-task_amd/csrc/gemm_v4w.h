@@ -80,9 +80,9 @@ __device__ __forceinline__ void v4w_loader(const GemmP& p, const unsigned lds0, 
         }
     };
     auto wait_pending = [&](int k_tiles) {
-        if (k_tiles >= 2) v3_wait_vm<2 * NI>();
-        else if (k_tiles == 1) v3_wait_vm<NI>();
-        else v3_wait_vm<0>();
+        if (k_tiles >= 2) v4_wait_vm<2 * NI>();
+        else if (k_tiles == 1) v4_wait_vm<NI>();
+        else v4_wait_vm<0>();
     };
     const int total = rounds * nk;
     set_unit(v4_tile_of(b, 0, gridDim.x, units));
