@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 NAMES = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
          "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
-STEPS, NB, LR = 200, 8, 2e-3
+# LR: at 2e-3 this problem is chaotic (a 1e-6 relative perturbation of the initial weights grows to 30 % of the loss by
+# step 130 in the CPU oracle itself); at 5e-4 a 1e-4 perturbation stays below 0.1 % of the loss over all 200 steps, so the
+# two implementations can be held to the same trajectory
+STEPS, NB, LR = 200, 8, 5e-4
 
 
 def _window(xs, lo, hi):
@@ -88,12 +91,12 @@ def test_two_hundred_steps_with_and_without_dropout_against_the_oracle():
     first, last = _window(oracle, 0, NB), _window(oracle, STEPS - 2 * NB, STEPS)
     assert last < 0.7 * first, "the oracle itself must learn on this problem (%.3f -> %.3f)" % (first, last)
     # no dropout: the same trajectory. Identical for the first steps (fp32 rounding only), then the two runs drift apart
-    # slowly (different summation orders feed back through 200 Adam steps): window means within 5 % + 0.02.
+    # slowly (different summation orders feed back through 200 Adam steps): window means within 2 % + 0.01.
     for i in range(3):
         assert abs(hip_off[i] - oracle[i]) <= 2e-4 * abs(oracle[i]), (i, hip_off[i], oracle[i])
     for lo in range(0, STEPS, 2 * NB):
         a, b = _window(hip_off, lo, lo + 2 * NB), _window(oracle, lo, lo + 2 * NB)
-        assert abs(a - b) <= 0.05 * b + 0.02, "steps %d-%d: HIP %.4f vs oracle %.4f" % (lo, lo + 2 * NB, a, b)
+        assert abs(a - b) <= 0.02 * b + 0.01, "steps %d-%d: HIP %.4f vs oracle %.4f" % (lo, lo + 2 * NB, a, b)
     # dropout on: learns (same start, clear decrease) ...
     assert abs(hip_on[0] - oracle[0]) <= 0.15 * oracle[0]
     on_last = _window(hip_on, STEPS - 2 * NB, STEPS)
