@@ -78,15 +78,18 @@ def test_two_hundred_steps_with_and_without_dropout_against_the_oracle():
                 loss.backward()
                 opt.step()
                 curve.append(loss.item())
+            with torch.no_grad():   # still in train mode, dropout probabilities as configured for this run
+                repeat = [sum(l.mean() for l in net(*dev_batches[0])).item() for _ in range(2)]
         finally:
             V._drop_p = orig
         net.eval()
         with torch.no_grad():
             clean = sum(sum(l.mean() for l in net(*b)).item() for b in dev_batches) / NB
-        return curve, clean
+            evals = [sum(l.mean() for l in net(*dev_batches[0])).item() for _ in range(2)]
+        return curve, clean, repeat, evals
 
-    hip_off, clean_off = run(False)
-    hip_on, clean_on = run(True)
+    hip_off, clean_off, repeat_off, _ = run(False)
+    hip_on, clean_on, repeat_on, eval_on = run(True)
 
     first, last = _window(oracle, 0, NB), _window(oracle, STEPS - 2 * NB, STEPS)
     assert last < 0.7 * first, "the oracle itself must learn on this problem (%.3f -> %.3f)" % (first, last)
@@ -107,10 +110,8 @@ def test_two_hundred_steps_with_and_without_dropout_against_the_oracle():
     # ... and in eval mode (no masks) its weights fit the training batches about as well as the no-dropout run's
     assert clean_on <= 1.5 * clean_off + 0.5, (clean_on, clean_off)
     assert clean_on < 0.8 * first
-    # fresh masks every step: with dropout the loss on the SAME batch differs between the two visits 8 steps apart by
-    # more than learning alone explains in the no-dropout run only if masks differ; a frozen mask would make the curve
-    # as smooth as the no-dropout one - compare the step-to-step roughness over the last 64 steps
-    def rough(c):
-        d = [abs(c[i] - c[i - NB]) for i in range(STEPS - 64, STEPS)]
-        return sum(d) / len(d)
-    assert rough(hip_on) > 1.5 * rough(hip_off), (rough(hip_on), rough(hip_off))
+    # fresh masks every step, none in eval mode - asked directly: the same batch twice WITHOUT an optimizer step in between
+    # gives two different training-mode losses (a frozen mask would repeat the value) and identical eval-mode losses
+    assert abs(repeat_on[0] - repeat_on[1]) > 1e-3 * abs(repeat_on[0]), repeat_on
+    assert abs(repeat_off[0] - repeat_off[1]) <= 1e-6 * abs(repeat_off[0]), repeat_off
+    assert abs(eval_on[0] - eval_on[1]) <= 1e-6 * abs(eval_on[0]), eval_on
