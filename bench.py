@@ -232,7 +232,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", choices=["fwd", "train"], default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "bf16x3", "bf16", "fp8"], default="f32",
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x6", "bf16x3", "bf16", "fp8", "mxfp8"], default="f32",
                     help="GEMM arithmetic: f32 = exact fp32 MFMA (default); bf16x6 = fp32 emulated with 6 bf16 "
                          "MFMA products (fp32-class); bf16x3 = 3 products")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra bf16x6 measurement")
@@ -720,6 +720,26 @@ def main():
                                              "eager launches vs the forward replayed as one HIP graph "
                                              "(vilbert/graphed.py GraphedForward)"}
             del f128, g128
+            # round 4: the MX (block-scaled) form of the same path - LayerNorm and the GELU epilogue emit the e4m3 codes the
+            # next linear consumes, the scaled MFMA applies the block scales (csrc/mx8.hip; bars: tests/test_mx_gpu.py)
+            _native.set_gemm_mode("mxfp8")
+            mx_dt = timed(fstep, 2, n_f)
+            mx_tf = 512 * n_f / mx_dt * f_total / 1e12
+            extra["fwd_mxfp8_b512"] = {"value": round(512 * n_f / mx_dt, 2), "unit": "samples/s",
+                                       "ms_per_step": round(1e3 * mx_dt / n_f, 3), "steps": n_f,
+                                       "speedup_vs_fp32": round(f_dt / mx_dt, 2), "model_tflops": round(mx_tf, 1),
+                                       "frac_of_fp8_mfma_peak": round(mx_tf / 5000.0, 4),
+                                       "note": "BASELINE configs[4]: forward with every nn.Linear whose K and N are multiples of "
+                                               "128 on MX e4m3 operands (one E8M0 scale per 32 K elements, applied by "
+                                               "v_mfma_scale_f32_32x32x64_f8f6f4), codes emitted by LayerNorm / the GELU "
+                                               "epilogue (no quantiser pass, no fp32 FFN activation); attention, LayerNorm "
+                                               "statistics and the residual stream stay fp32; fp8 dense MFMA peak 5000 TF"}
+            gmx, _, _ = forward_workload(128, graph=True)
+            gmx_dt = timed(gmx, 2, n128)
+            extra["fwd_mxfp8_b128"] = {"value": round(128 * n128 / gmx_dt, 2), "unit": "samples/s",
+                                       "ms_per_step": round(1e3 * gmx_dt / n128, 3), "steps": n128,
+                                       "note": "per-GPU share of BASELINE configs[4] (128 per GPU) in the MX mode, one HIP graph"}
+            del gmx
         finally:
             _native.set_gemm_mode("f32")
         del fstep, fmodel
@@ -798,7 +818,7 @@ def main():
             line["alt_gemm_modes"] = alt
         if host_leg is not None:
             line["host_inputs"] = host_leg
-        if args.gemm_mode == "fp8":
+        if args.gemm_mode in ("fp8", "mxfp8"):
             line["dtype"] = "OCP e4m3 operands (row-wise scales), fp32 accumulate, forward linears only - NOT inside the " \
                             "1e-4 parity bar, see tests/test_fp8_gpu.py for its measured drift"
             line["roofline"].update(peak=5000.0, frac=round(achieved / 5000.0, 4),

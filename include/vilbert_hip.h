@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 13
+#define VB_ABI_VERSION 14
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -225,6 +225,59 @@ typedef struct {
 } vb_linear_fp8_args;
 
 int vb_linear_fwd_fp8(void* stream, const vb_linear_fp8_args* a);
+
+/* ---- MX (OCP microscaling) e4m3 forward path, round 4 (csrc/mx8.hip; numerics: oracle/fp8_oracle.py `mx_*`). Same place
+ * in the model as the row-scaled path above (every forward nn.Linear of vilbert.py:424-517, 571-694, 738-900 in the fp8
+ * mode), different format: one power-of-two scale per 32 consecutive K elements, applied by the scaled MFMA itself - so
+ * a producer that holds 32 consecutive columns of an output row (a GEMM epilogue, LayerNorm) emits the codes the next
+ * linear consumes and no fp32 tensor / separate quantiser pass sits between two linears.
+ *
+ * Format: codes [rows][K] e4m3fn bytes (K % 128 == 0); scales as uint32 words S[K / 128][scale_rows]: word (kt, r) holds
+ * the E8M0 bytes of row r's blocks 4 kt .. 4 kt + 3 (byte b = block 4 kt + b; value 2^(byte - 127); the smallest power of
+ * two with amax_block / scale <= 448, byte 0 for an all-zero block). scale_rows >= rows is the row stride of a scale plane.
+ *
+ * vb_quantize_rows_mx: fp32 rows -> that format (weights: once per optimizer step; activations no producer quantises). */
+int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const float* x, int64_t ldx, uint8_t* q, int64_t ldq,
+                        uint32_t* scales, int64_t scale_rows);
+
+/* nn.Linear forward on MX operands: v = act(A W^T + bias) (+ residual), A [M][K] and W [N][K] in the format above,
+ * K % 128 == 0, N % 128 == 0; a_srows >= M rounded up to 256, w_srows >= N (both % 4 == 0; the kernel fetches the scale
+ * words of a 256-row / 128-row tile as one piece). Any subset (at least one) of three outputs of the SAME values v:
+ *   C  fp32 [M][N] (ldc floats);  Cb bf16 [M][N] (round to nearest even, ldb16 elements);
+ *   Cq + c_scales: v re-quantised to MX along N (the K of the next linear), ldq bytes % 16 == 0, c_srows >= M.
+ * act: VB_ACT_NONE or VB_ACT_GELU. No dropout: this is the inference path of BASELINE configs[4]. */
+typedef struct {
+    const uint8_t* A;
+    int64_t lda;
+    const uint32_t* a_scales;
+    int64_t a_srows;
+    const uint8_t* W;
+    int64_t ldw;
+    const uint32_t* w_scales;
+    int64_t w_srows;
+    const float* bias;       /* [N] or NULL */
+    const float* residual;   /* fp32 [M][N] or NULL */
+    int64_t ldr;
+    float* C;                /* or NULL */
+    int64_t ldc;
+    uint16_t* Cb;            /* or NULL */
+    int64_t ldb16;
+    uint8_t* Cq;             /* or NULL */
+    int64_t ldq;
+    uint32_t* c_scales;
+    int64_t c_srows;
+    int64_t M, N, K;
+    int32_t act;
+} vb_linear_mx_args;
+
+int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a);
+
+/* BertLayerNorm forward (vilbert.py:313-317, as vb_layernorm_fwd: y = LN(x (+ x2))) that ALSO emits every output row in
+ * the MX format above for the linears consuming it (n_cols % 128 == 0; scale_rows >= rows). Bit-identical to
+ * vb_layernorm_fwd followed by vb_quantize_rows_mx on y. */
+int vb_layernorm_fwd_mx(void* stream, int64_t rows, int32_t n_cols, const float* x, const float* x2,
+                        const float* gamma, const float* beta, float eps, float* y, uint8_t* q, int64_t ldq,
+                        uint32_t* scales, int64_t scale_rows);
 
 /* BertLayerNorm forward (vilbert.py:313-317, as vb_layernorm_fwd: y = LN(x (+ x2))) that ALSO emits the e4m3 codes and
  * scale of every output row for the fp8 linears consuming it (inference in fp8 mode): q[r][0..n_cols), row stride ldq

@@ -72,3 +72,74 @@ def linear_fp8(x, w, bias=None):
     if bias is not None:
         y = y + np.asarray(bias, dtype=np.float64)[None, :]
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MX (OCP Microscaling Formats v1.0, "MXFP8 E4M3") statement of csrc/mx8.hip - round 4. Again not a reference feature
+# (PARITY UNPINNED against the reference by construction); pinned here: the element format (e4m3fn, as above, against
+# torch.float8_e4m3fn), the shared scale (E8M0: an 8-bit biased power of two, value 2^(byte - 127)) and the block of 32
+# consecutive elements along the contraction dimension. The spec leaves the choice of the shared exponent to the
+# producer; this path's rule is
+#     e = the smallest integer with amax_block / 2^e <= 448   (nothing ever saturates; the spec's own example rule
+#         floor(log2 amax) - 8 clips the top of the block instead),  byte = max(e + 127, 0)
+# computed from the BITS of amax exactly as the kernels do (448 = 1.75 x 2^8), elements = e4m3_rne(x * 2^-e) - the scaling
+# is exact, so there is exactly one rounding per element.
+# ---------------------------------------------------------------------------------------------------------------------
+MX_BLOCK = 32
+
+
+def mx_scale_bytes(amax):
+    """float32 block maxima (>= 0) -> uint8 E8M0 bytes."""
+    u = np.asarray(amax, dtype=np.float32).view(np.uint32).astype(np.int64)
+    b = (u >> 23) - 8 + ((u & 0x7FFFFF) > 0x600000)
+    return np.clip(b, 0, 254).astype(np.uint8)
+
+
+def mx_quantize(x):
+    """x [rows, K] float32 (K % 32 == 0) -> (codes uint8 [rows, K], scale bytes uint8 [rows, K / 32])."""
+    x = np.asarray(x, dtype=np.float32)
+    rows, K = x.shape
+    blocks = x.reshape(rows, K // MX_BLOCK, MX_BLOCK)
+    byte = mx_scale_bytes(np.max(np.abs(blocks), axis=2))
+    inv = np.ldexp(np.float32(1.0), 127 - byte.astype(np.int32)).astype(np.float32)       # 2^-e, exact
+    y = (blocks * inv[:, :, None]).astype(np.float32)                                        # exact scaling
+    return e4m3_encode(y).reshape(rows, K), byte
+
+
+def mx_dequantize(codes, byte):
+    """(codes [rows, K], scale bytes [rows, K / 32]) -> float64 values."""
+    rows, K = codes.shape
+    v = e4m3_decode(codes).astype(np.float64).reshape(rows, K // MX_BLOCK, MX_BLOCK)
+    return (v * np.ldexp(1.0, byte.astype(np.int32) - 127)[:, :, None]).reshape(rows, K)
+
+
+def mx_scale_words(byte, scale_rows=None):
+    """Scale bytes [rows, K / 32] -> the kernels' layout: uint32 words [K / 128, scale_rows], word (kt, r) = bytes of row
+    r's blocks 4 kt .. 4 kt + 3 (little endian: byte b of the word = block 4 kt + b); rows beyond `rows` are zero here
+    (the kernels leave them unwritten)."""
+    rows, nb = byte.shape
+    assert nb % 4 == 0
+    scale_rows = rows if scale_rows is None else scale_rows
+    w = byte.reshape(rows, nb // 4, 4).astype(np.uint32)
+    words = w[:, :, 0] | (w[:, :, 1] << 8) | (w[:, :, 2] << 16) | (w[:, :, 3] << 24)
+    out = np.zeros((nb // 4, scale_rows), dtype=np.uint32)
+    out[:, :rows] = words.T
+    return out
+
+
+def mx_words_to_bytes(words, rows):
+    """Inverse of mx_scale_words for the first `rows` rows."""
+    w = np.asarray(words, dtype=np.uint32)[:, :rows].T            # [rows, K / 128]
+    b = np.stack([(w >> (8 * i)) & 0xFF for i in range(4)], axis=2)
+    return b.reshape(rows, -1).astype(np.uint8)
+
+
+def linear_mx(x, w, bias=None):
+    """Reference result of vb_linear_fwd_mx before the activation: float64 [M, N] (exact sums of the dequantised
+    operands; the kernel accumulates in fp32 inside the scaled MFMA)."""
+    qa, sa = mx_quantize(x)
+    qw, sw = mx_quantize(w)
+    y = mx_dequantize(qa, sa) @ mx_dequantize(qw, sw).T
+    if bias is not None:
+        y = y + np.asarray(bias, dtype=np.float64)[None, :]
+    return y

@@ -33,7 +33,7 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
+EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_quantize_rows_mx", "vb_linear_fwd_mx", "vb_layernorm_fwd_mx", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd"]
 
 
@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 13
+    assert lib.vb_abi_version() == 14
     prev = native.set_gemm_mode("bf16x6")
     assert native.set_gemm_mode(prev) == "bf16x6" and native.set_gemm_mode(prev) == prev
     assert lib.vb_error_string(0) == b"ok"
@@ -64,7 +64,7 @@ def test_struct_layouts_match_the_header(native):
                            ("vb_attention_grads", native.AttentionGrads),
                            ("vb_linear_bwd_input_args", native.LinearBwdInputArgs),
                            ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs),
-                           ("vb_linear_fp8_args", native.LinearFp8Args),
+                           ("vb_linear_fp8_args", native.LinearFp8Args), ("vb_linear_mx_args", native.LinearMxArgs),
                            ("vb_adamw_tensor", native.AdamWTensor), ("vb_concap_batch", native.ConcapBatch)):
         body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", text))[struct]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -86,6 +86,7 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.vb_attention_bwd(None, None, None) == -1
     assert lib.vb_linear_bwd_input(None, None) == -1 and lib.vb_linear_bwd_weight(None, None) == -1
     assert lib.vb_concap_finish_batch(None, None) == -1
+    assert lib.vb_linear_fwd_mx(None, None) == -1 and lib.vb_quantize_rows_mx(None, 0, 0, None, 0, None, 0, None, 0) == -1
     assert lib.vb_xent_fwd(None, 1, 0, None, 0, None, -1, None, None, None, None) == -1
     assert lib.vb_layernorm_bwd_workspace(16, 768) == 4 * 2 * 768
     assert lib.vb_layernorm_bwd_workspace(17, 768) == 8 * 2 * 768
@@ -151,13 +152,25 @@ def test_short_sequence_attention_forward_keeps_three_blocks_per_cu(native):
     assert vgprs + agprs <= 168 and occ >= 3, (vgprs, agprs, occ)
 
 
+def test_mx_gemm_keeps_ten_waves_per_cu(native):
+    """gemm_mx_kernel = 8 MFMA waves + 2 loader waves in ONE block per CU: three waves share a SIMD, so the kernel must stay
+    within 168 registers and must not spill (an `if` around the prefetch of the last K tile once made hipcc copy a whole
+    fragment set per K step and park two accumulators in scratch inside the loop)."""
+    text = open(os.path.join(os.path.dirname(native.LIB_PATH), "mx8.resource.txt")).read()
+    found = re.findall(r"Function Name: \S*gemm_mx_kernel\S*.*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
+                       r"Occupancy \[waves/SIMD\]: (\d+)", text, flags=re.S)
+    assert found, "kernel not found in mx8.resource.txt"
+    vgprs, agprs, scratch, occ = (int(v) for v in found[0])
+    assert vgprs + agprs <= 168 and scratch == 0 and occ >= 3, (vgprs, agprs, scratch, occ)
+
+
 def test_gemm_mode_names_round_trip_without_a_gpu(native):
     """Mode selection is host state (C side: arithmetic of vb_linear_*; Python side: the fp8 forward switch)."""
     first = native.set_gemm_mode("f32")
     try:
-        for mode in ("bf16x6", "bf16x3", "bf16", "fp8", "fp8+bf16", "f32"):
+        for mode in ("bf16x6", "bf16x3", "bf16", "fp8", "fp8+bf16", "mxfp8", "f32"):
             native.set_gemm_mode(mode)
-            assert native.fp8_enabled() == mode.startswith("fp8")
+            assert native.fp8_enabled() == ("fp8" in mode) and native.mx_enabled() == (mode == "mxfp8")
             assert native.set_gemm_mode(mode) == mode
         with pytest.raises(KeyError):
             native.set_gemm_mode("fp4")

@@ -54,3 +54,47 @@ def test_linear_fp8_close_to_fp32():
     y = x.astype(np.float64) @ w.astype(np.float64).T
     rel = np.linalg.norm(y8 - y) / np.linalg.norm(y)
     assert rel < 0.05, rel
+
+
+# ---- MX (block-scaled) statement, round 4 -----------------------------------------------------------------------------
+def test_mx_scale_rule_is_the_smallest_power_of_two_that_fits():
+    rng = np.random.default_rng(0)
+    amax = np.concatenate([np.exp2(rng.uniform(-40, 40, 20000)).astype(np.float32),
+                           np.array([448.0, 449.0, 447.99, 224.0, 224.01, 1.0, 1.75, 1.7500001, 0.875, 3.5], np.float32)])
+    byte = F.mx_scale_bytes(amax).astype(np.int32)
+    scale = np.ldexp(1.0, byte - 127)
+    assert (amax.astype(np.float64) / scale <= 448.0).all()                 # fits ...
+    assert (amax.astype(np.float64) / (scale / 2) > 448.0).all()            # ... and the next smaller power of two does not
+    assert F.mx_scale_bytes(np.float32(0.0)) == 0 and F.mx_scale_bytes(np.float32(448.0)) == 127
+    assert F.mx_scale_bytes(np.float32(449.0)) == 128 and F.mx_scale_bytes(np.float32(1e-45)) == 0
+
+
+def test_mx_codes_are_torch_float8_of_the_scaled_block_and_round_trip():
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((64, 256)) * np.exp2(rng.integers(-12, 12, (64, 8)).repeat(32, axis=1))).astype(np.float32)
+    x[3] = 0
+    x[5, 32:64] = 0
+    q, b = F.mx_quantize(x)
+    inv = np.ldexp(np.float32(1), 127 - b.astype(np.int32)).repeat(32, axis=1).astype(np.float32)
+    want = torch.from_numpy(x * inv).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(q, want)
+    assert (b[3] == 0).all() and b[5, 1] == 0 and (q[3] == 0).all()
+    back = F.mx_dequantize(q, b)
+    amax = np.abs(x.reshape(64, 8, 32)).max(axis=2).repeat(32, axis=1)
+    # one e4m3 rounding relative to the block: <= 2^-4 relative for normals, <= 2^-10 of the block scale for subnormals
+    scale = np.ldexp(1.0, b.astype(np.int32) - 127).repeat(32, axis=1)
+    assert (np.abs(back - x) <= np.abs(x) / 16 + scale / 1024 + 1e-300).all()
+    assert (np.abs(back) <= amax * (1 + 1 / 16) + 1e-300).all() and (np.abs(back) <= 448 * scale).all()
+    words = F.mx_scale_words(b, 256)
+    assert words.shape == (2, 256) and words[0, 5] == (int(b[5, 0]) | int(b[5, 1]) << 8 | int(b[5, 2]) << 16 | int(b[5, 3]) << 24)
+    assert np.array_equal(F.mx_words_to_bytes(words, 64), b)
+
+
+def test_mx_linear_is_closer_to_fp32_than_its_bound():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((32, 512)).astype(np.float32)
+    w = (rng.standard_normal((48, 512)) * 0.05).astype(np.float32)
+    y = F.linear_mx(x, w)
+    exact = x.astype(np.float64) @ w.astype(np.float64).T
+    rel = np.linalg.norm(y - exact) / np.linalg.norm(exact)
+    assert 1e-4 < rel < 0.06, rel

@@ -6,6 +6,7 @@
 // passes, so every element is read from HBM once and written once. Statistics are two-pass
 // (mean, then the mean of squared deviations) exactly as the reference computes them.
 #include "common.h"
+#include "mx8.h"
 #include "rng.h"
 
 namespace {
@@ -18,7 +19,8 @@ template <int NV>
 __device__ __forceinline__ void ln_finish(f32x4 (&x)[NV], int n_cols, int lane, const float* gamma,
                                           const float* beta, float eps, float* yrow, float* mean_out,
                                           float* rstd_out, float* presum_row = nullptr,
-                                          unsigned char* qrow = nullptr, float* qscale = nullptr) {
+                                          unsigned char* qrow = nullptr, float* qscale = nullptr,
+                                          unsigned* mx_words = nullptr, long mx_rows = 0) {
     if (presum_row != nullptr) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -61,7 +63,19 @@ __device__ __forceinline__ void ln_finish(f32x4 (&x)[NV], int n_cols, int lane, 
                 amax = fmaxf(amax, fmaxf(fmaxf(fabsf(x[i][0]), fabsf(x[i][1])), fmaxf(fabsf(x[i][2]), fabsf(x[i][3]))));
         }
     }
-    if (qrow != nullptr) {
+    if (qrow != nullptr && mx_words != nullptr) {
+        // MX codes of the row (mx8.h): chunk i = columns 256 i .. 256 i + 255, a 32-column block = 8 consecutive lanes;
+        // mx_words = scale plane base + this row, plane stride mx_rows words (bit-identical to vb_quantize_rows_mx on y)
+        const int nkt = n_cols >> 7;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            const bool ok = col < n_cols;
+            const int kt = 2 * i + (lane >> 5);
+            mx_quant_chunk(x[i], ok, lane, kt, nkt, reinterpret_cast<unsigned*>(qrow + (ok ? col : 0)),
+                           mx_words + (long)(kt < nkt ? kt : 0) * mx_rows);
+        }
+    } else if (qrow != nullptr) {
         // the row's e4m3 codes + scale for the fp8 linears that consume it (same recipe, same bits as
         // vb_quantize_rows_fp8 applied to the stored row - csrc/fp8.hip)
 #pragma unroll
@@ -88,7 +102,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(long rows, int n_cols, c
                                                         const float* __restrict__ beta, float eps,
                                                         float* __restrict__ y, float* mean, float* rstd,
                                                         unsigned char* __restrict__ q, long ldq,
-                                                        float* __restrict__ qscale) {
+                                                        float* __restrict__ qscale, unsigned* __restrict__ mxs = nullptr,
+                                                        long mxs_rows = 0) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -104,7 +119,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(long rows, int n_cols, c
         }
     }
     ln_finish<NV>(v, n_cols, lane, gamma, beta, eps, y + row * n_cols, mean ? mean + row : nullptr,
-                  rstd ? rstd + row : nullptr, nullptr, q ? q + row * ldq : nullptr, q ? qscale + row : nullptr);
+                  rstd ? rstd + row : nullptr, nullptr, q ? q + row * ldq : nullptr, (q && qscale) ? qscale + row : nullptr,
+                  mxs ? mxs + row : nullptr, mxs_rows);
 }
 
 // reference vilbert.py:346-367
@@ -262,6 +278,28 @@ extern "C" int vb_layernorm_fwd_fp8(void* stream, int64_t rows, int32_t n_cols, 
     VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, (long)rows,
                                                       n_cols, x, x2, gamma, beta, eps, y, (float*)nullptr,
                                                       (float*)nullptr, q, (long)ldq, qscale));
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+// LayerNorm forward that also emits its output rows in the MX e4m3 format (mx8.hip) for the linears consuming it; the
+// fp32 row stays for the residual path. Bit-identical to vb_layernorm_fwd followed by vb_quantize_rows_mx on y.
+extern "C" int vb_layernorm_fwd_mx(void* stream, int64_t rows, int32_t n_cols, const float* x, const float* x2,
+                                   const float* gamma, const float* beta, float eps, float* y, uint8_t* q, int64_t ldq,
+                                   uint32_t* scales, int64_t scale_rows) {
+    if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || q == nullptr || scales == nullptr || rows <= 0)
+        return VB_E_BADARG;
+    if (int e = check_cols(n_cols)) return e;
+    if (n_cols % 128 != 0 || scale_rows < rows) return VB_E_RANGE;
+    if (!vb_aligned16(x) || !vb_aligned16(y) || !vb_aligned16(gamma) || !vb_aligned16(beta) ||
+        (x2 != nullptr && !vb_aligned16(x2)) || ldq < n_cols || ldq % 4 != 0 || (reinterpret_cast<uintptr_t>(q) & 3u) != 0 ||
+        (reinterpret_cast<uintptr_t>(scales) & 3u) != 0)
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm_kernel<NV>), grid, block, 0, st, (long)rows,
+                                                      n_cols, x, x2, gamma, beta, eps, y, (float*)nullptr,
+                                                      (float*)nullptr, q, (long)ldq, (float*)nullptr, scales, (long)scale_rows));
     VB_LAUNCH_CHECK();
     return 0;
 }

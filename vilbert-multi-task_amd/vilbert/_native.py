@@ -57,6 +57,24 @@ class LinearFp8Args(ctypes.Structure):
     ]
 
 
+class LinearMxArgs(ctypes.Structure):
+    """vb_linear_mx_args"""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_int64),
+        ("a_scales", ctypes.c_void_p), ("a_srows", ctypes.c_int64),
+        ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+        ("w_scales", ctypes.c_void_p), ("w_srows", ctypes.c_int64),
+        ("bias", _c_f32p),
+        ("residual", _c_f32p), ("ldr", ctypes.c_int64),
+        ("C", _c_f32p), ("ldc", ctypes.c_int64),
+        ("Cb", ctypes.c_void_p), ("ldb16", ctypes.c_int64),
+        ("Cq", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+        ("c_scales", ctypes.c_void_p), ("c_srows", ctypes.c_int64),
+        ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+        ("act", ctypes.c_int32),
+    ]
+
+
 class AttentionArgs(ctypes.Structure):
     """vb_attention_args"""
     _fields_ = [
@@ -156,6 +174,9 @@ SIGNATURES = {
     "vb_quantize_rows_fp8": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P]),
     "vb_linear_fwd_fp8": (ctypes.c_int, [_P, ctypes.POINTER(LinearFp8Args)]),
     "vb_layernorm_fwd_fp8": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P]),
+    "vb_quantize_rows_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _I64]),
+    "vb_linear_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(LinearMxArgs)]),
+    "vb_layernorm_fwd_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P, _I64]),
     "vb_act_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "vb_dropout": (ctypes.c_int, [_P, _I64, _P, _P, _P, _F32, _U64]),
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),
@@ -192,11 +213,12 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 13:
+        if handle.vb_abi_version() != 14:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
-        if os.environ.get("VB_GEMM_MODE") == "fp8":
+        if os.environ.get("VB_GEMM_MODE") in ("fp8", "mxfp8"):
             _FP8["on"] = True
+            _FP8["mx"] = os.environ.get("VB_GEMM_MODE") == "mxfp8"
     return _lib
 
 
@@ -279,7 +301,7 @@ def set_gemm_v4(mode):
 
 
 GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
-_FP8 = {"on": False}
+_FP8 = {"on": False, "mx": False}
 
 
 def set_gemm_mode(mode):
@@ -287,13 +309,17 @@ def set_gemm_mode(mode):
     "f32" exact-fp32 MFMA | "bf16x6" | "bf16x3" | "bf16": arithmetic of every vb_linear_* launch (C side);
     "fp8": FORWARD linears whose shape allows it run on quantised e4m3 operands (vb_linear_fwd_fp8, host-side weight
     cache in ops.py); everything else - backward GEMMs, ineligible shapes - stays exact fp32;
-    "fp8+bf16": fp8 forward as above, every other GEMM (backward, ineligible shapes) in the bf16 mode."""
-    if mode not in GEMM_MODES and mode not in ("fp8", "fp8+bf16"):
-        raise KeyError("unknown GEMM mode %r (f32 | bf16x6 | bf16x3 | bf16 | fp8 | fp8+bf16)" % (mode,))
-    prev_fp8 = _FP8["on"]
-    _FP8["on"] = mode in ("fp8", "fp8+bf16")
-    prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode == "fp8" else "bf16" if mode == "fp8+bf16" else mode])
+    "fp8+bf16": fp8 forward as above, every other GEMM (backward, ineligible shapes) in the bf16 mode;
+    "mxfp8": as "fp8" with the MX block-scaled kernels wherever K % 128 == 0 and N % 128 == 0 (round 4; inference)."""
+    if mode not in GEMM_MODES and mode not in ("fp8", "fp8+bf16", "mxfp8"):
+        raise KeyError("unknown GEMM mode %r (f32 | bf16x6 | bf16x3 | bf16 | fp8 | fp8+bf16 | mxfp8)" % (mode,))
+    prev_fp8, prev_mx = _FP8["on"], _FP8["mx"]
+    _FP8["on"] = mode in ("fp8", "fp8+bf16", "mxfp8")
+    _FP8["mx"] = mode == "mxfp8"
+    prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode in ("fp8", "mxfp8") else "bf16" if mode == "fp8+bf16" else mode])
     prev_name = {v: k for k, v in GEMM_MODES.items()}[prev]
+    if prev_mx:
+        return "mxfp8"
     if prev_fp8:
         return "fp8+bf16" if prev_name == "bf16" else "fp8"
     return prev_name
@@ -301,6 +327,13 @@ def set_gemm_mode(mode):
 
 def fp8_enabled():
     return _FP8["on"]
+
+
+def mx_enabled():
+    """MX e4m3 forward mode (set_gemm_mode("mxfp8")): linears whose shape allows it run on block-scaled operands
+    (csrc/mx8.hip), LayerNorm and GEMM epilogues emit the codes the next linear consumes; the remaining eligible shapes use
+    the row-scaled fp8 kernel, everything else stays fp32."""
+    return _FP8["mx"]
 
 
 # Parameters are rewritten through raw pointers by the native optimizer, behind torch's version counters; caches of

@@ -31,7 +31,11 @@ def ffn(x, w1, b1, act, w2, b2, drop_p=0.0):
     """dropout(act(x @ w1.T + b1) @ w2.T + b2, drop_p) + x  (the block in front of the output LayerNorm)."""
     if _needs_grad(x, w1, b1, w2, b2):
         return A.FFNFn.apply(x, w1, b1, w2, b2, act, drop_p)
-    h = ops.linear_fwd(x, [w1], [b1], act)[0]
+    # MX mode (inference): the activation of the up-projection leaves its GEMM as MX codes for the down-projection - it is
+    # never written in fp32 and never re-read by a quantiser
+    mx = (drop_p == 0.0 and ops.mx_eligible(w1.shape[1], w1.shape[0], act, biases=[b1])
+          and ops.mx_eligible(w2.shape[1], w2.shape[0], None, biases=[b2]) and x.is_cuda)
+    h = ops.linear_fwd(x, [w1], [b1], act, out="mx" if mx else "f32")[0]
     seed = A.next_seed() if drop_p > 0.0 else 0
     return ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)[0]
 

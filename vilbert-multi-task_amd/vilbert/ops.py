@@ -182,9 +182,131 @@ def _linear_fwd_fp8(x, x2, M, K, weights, biases, n_out, y, ldc, act, residual, 
            2.0 * M * n_out * K, ("fwd_fp8", M, n_out, K, 1))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# MX e4m3 forward path (round 4; kernels csrc/mx8.hip, numerics oracle/fp8_oracle.py `mx_*`): block-scaled operands, the
+# producers (LayerNorm, a GEMM epilogue) emit the codes the next linear consumes
+# ---------------------------------------------------------------------------------------------------------------
+MX_BLOCK = 32            # elements per scale
+MX_K_MULTIPLE = 128      # K of a linear (= the 4 scale bytes of one uint32 word), also the GEMM's column tile
+_MX_WEIGHTS = {}
+
+
+class MxRows(object):
+    """A [rows, K] activation in the MX format: `q` codes [rows, K] uint8, `s` scale words [K / 128, srows] int32 (word
+    (kt, r) = the four E8M0 bytes of row r's K range [128 kt, 128 kt + 128)); `lead` = the leading shape of the tensor it
+    stands for. Not a torch tensor: only `linear_fwd` consumes it."""
+    __slots__ = ("q", "s", "srows", "rows", "K", "lead")
+
+    def __init__(self, rows, K, device, lead):
+        self.rows, self.K, self.lead = rows, K, tuple(lead)
+        self.srows = (rows + 255) // 256 * 256          # the GEMM fetches the scale words of a 256-row tile as one piece
+        self.q = torch.empty((rows, K), dtype=torch.uint8, device=device)
+        self.s = torch.empty((K // MX_K_MULTIPLE, self.srows), dtype=torch.int32, device=device)
+
+    @property
+    def shape(self):
+        return self.lead + (self.K,)
+
+
+def quantize_rows_mx(x2, lead=None, out=None):
+    """x2 [rows, K] fp32 (row stride allowed, K % 128 == 0) -> MxRows."""
+    rows, K = x2.shape
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m = out if out is not None else MxRows(rows, K, x2.device, lead if lead is not None else (rows,))
+    N.check(N.lib().vb_quantize_rows_mx(N.stream_ptr(), rows, K, N.dev_f32(x2, "mx quantise input"), x2.stride(0),
+                                        m.q.data_ptr(), m.q.stride(0), m.s.data_ptr(), m.srows), "vb_quantize_rows_mx")
+    return m
+
+
+def mx_cache_clear():
+    _MX_WEIGHTS.clear()
+
+
+def _mx_weights(weights, biases):
+    """MX copy of the (stacked) weight, cached like `_fp8_weights` (same invalidation rules)."""
+    key = tuple(w.data_ptr() for w in weights)
+    vers = tuple(w._version for w in weights) + tuple(-1 if b is None else b._version for b in (biases or []))
+    seg_n, K = weights[0].shape
+    n = seg_n * len(weights)
+    hit = _MX_WEIGHTS.get(key)
+    if hit is not None and hit[2].q.shape != (n, K):
+        hit = None
+    if hit is not None and hit[0] == vers and hit[1] == _WEIGHTS_EPOCH[0]:
+        return hit[2], hit[3]
+    dev = weights[0].device
+    if hit is not None:
+        m, bias = hit[2], hit[3]                    # refresh in place (captured graphs keep the addresses)
+    else:
+        dead = [k for k, e in _MX_WEIGHTS.items() if all(r() is None for r in e[5])]
+        for k in dead:
+            del _MX_WEIGHTS[k]
+        m, bias = MxRows(n, K, dev, (n,)), None
+    with torch.no_grad():
+        cat = weights[0].detach() if len(weights) == 1 else torch.cat([w.detach() for w in weights])
+        quantize_rows_mx(cat, out=m)
+        if biases is not None and all(b is not None for b in biases):
+            bcat = biases[0].detach() if len(biases) == 1 else torch.cat([b.detach() for b in biases])
+            if bias is None or len(biases) == 1:
+                bias = bcat
+            else:
+                bias.copy_(bcat)
+        elif biases is not None and any(b is not None for b in biases):
+            raise RuntimeError("linear (mx): either every weight segment has a bias or none")
+        else:
+            bias = None
+    _MX_WEIGHTS[key] = (vers, _WEIGHTS_EPOCH[0], m, bias, [w.detach() for w in weights], [weakref.ref(w) for w in weights])
+    return m, bias
+
+
+def mx_eligible(K, n_out, act=None, drop_p=0.0, want_pre=False, biases=None):
+    uniform_bias = biases is None or all(b is None for b in biases) or all(b is not None for b in biases)
+    return (N.mx_enabled() and not torch.is_grad_enabled() and K % MX_K_MULTIPLE == 0 and n_out % MX_K_MULTIPLE == 0
+            and act in (None, "none", "gelu") and drop_p == 0.0 and not want_pre and uniform_bias)
+
+
+def _mx_of(x, x2, M, K, lead):
+    """MX form of the input: the object itself, the codes its producer attached (LayerNorm), or a quantiser pass."""
+    if isinstance(x, MxRows):
+        return x
+    tag = getattr(x, "_vb_mx", None)
+    if tag is not None and tag[1] == x._version and tag[0].rows == M and tag[0].K == K and x.is_contiguous():
+        return tag[0]
+    return quantize_rows_mx(x2, lead)
+
+
+def _linear_fwd_mx(x, x2, M, K, lead, weights, biases, n_out, act, residual, out):
+    """out: "f32" -> fp32 tensor, "mx" -> MxRows of the result (no fp32 copy), "bf16" -> bfloat16 tensor."""
+    wm, bias = _mx_weights(weights, biases)
+    xm = _mx_of(x, x2, M, K, lead)
+    a = N.LinearMxArgs()
+    a.A, a.lda, a.a_scales, a.a_srows = xm.q.data_ptr(), K, xm.s.data_ptr(), xm.srows
+    a.W, a.ldw, a.w_scales, a.w_srows = wm.q.data_ptr(), K, wm.s.data_ptr(), wm.srows
+    a.bias = N.dev_f32(bias, "linear bias") if bias is not None else None
+    if residual is not None:
+        a.residual, a.ldr = N.dev_f32(residual, "linear residual"), n_out
+    dev = xm.q.device
+    if out == "mx":
+        y = MxRows(M, n_out, dev, lead)
+        a.Cq, a.ldq, a.c_scales, a.c_srows = y.q.data_ptr(), n_out, y.s.data_ptr(), y.srows
+    elif out == "bf16":
+        y = torch.empty(tuple(lead) + (n_out,), dtype=torch.bfloat16, device=dev)
+        a.Cb, a.ldb16 = y.data_ptr(), n_out
+    else:
+        y = torch.empty(tuple(lead) + (n_out,), dtype=torch.float32, device=dev)
+        a.C, a.ldc = y.data_ptr(), n_out
+    a.M, a.N, a.K = M, n_out, K
+    a.act = N.ACT_CODES[act]
+    _timed(lambda: N.check(N.lib().vb_linear_fwd_mx(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd_mx"),
+           2.0 * M * n_out * K, ("fwd_mx", M, n_out, K, 1))
+    return y
+
+
 def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0,
-               want_act_grad=False, pad_cols=False):
+               want_act_grad=False, pad_cols=False, out="f32"):
     """act(x @ cat(weights).T + cat(biases)) (+ residual).
+    out: "f32" (default); in the MX mode (set_gemm_mode("mxfp8"), no grad) an eligible linear may instead return its
+    result as "mx" (MxRows: the codes the next linear consumes, no fp32 tensor) or "bf16"; x may be an MxRows.
     want_act_grad: the second return value is act'(pre-activation) instead of the pre-activation (the backward
     of the activation then is one multiply in the epilogue of linear_bwd_input(mul=...)).
     pad_cols: a 2-D result whose width is not a multiple of 4 (the 30522-wide MLM logits) is returned as a view of a
@@ -202,9 +324,26 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
         raise RuntimeError("linear: at most %d weight segments per launch" % N.VB_MAX_SEGMENTS)
     if x.shape[-1] != K:
         raise RuntimeError("linear: input has %d features, weight expects %d" % (x.shape[-1], K))
+    n_out = nseg * seg_n
+    if isinstance(x, MxRows) or (N.mx_enabled() and mx_eligible(K, n_out, act, drop_p, want_preact or want_act_grad, biases)
+                                 and x.is_cuda):
+        if not mx_eligible(K, n_out, act, drop_p, want_preact or want_act_grad, biases):
+            raise RuntimeError("linear: an MX input needs an MX-eligible linear (K, N multiples of 128, no dropout)")
+        for w in weights:
+            if w.shape != (seg_n, K) or not w.is_contiguous():
+                raise RuntimeError("linear: weight segments must be contiguous and equally shaped")
+        if isinstance(x, MxRows):
+            x2, M, lead = None, x.rows, x.lead
+        else:
+            x2, _, lead = _row_view(x, K)
+            M = x2.shape[0]
+        if residual is not None:
+            residual = _contig(residual)
+            if residual.numel() != M * n_out:
+                raise RuntimeError("linear: residual shape mismatch")
+        return _linear_fwd_mx(x, x2, M, K, lead, weights, biases, n_out, act, residual, out), None
     x2, lda, lead = _row_view(x, K)
     M = x2.shape[0]
-    n_out = nseg * seg_n
     ldc = n_out
     if pad_cols and n_out % 4 != 0 and len(lead) == 1 and residual is None and not (want_preact or want_act_grad) \
             and drop_p == 0.0:
@@ -362,6 +501,19 @@ def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
     rows, cols = _rows(x)
     y = torch.empty_like(x)
     mean = rstd = None
+    if N.mx_enabled() and not want_stats and not torch.is_grad_enabled() and cols % MX_K_MULTIPLE == 0 and x.is_cuda:
+        # inference in the MX mode: the LayerNorm kernel also emits its output rows as MX codes + scale words
+        if x2 is not None:
+            x2 = _contig(x2)
+            if x2.shape != x.shape:
+                raise RuntimeError("layernorm: x2 shape mismatch")
+        m = MxRows(rows, cols, x.device, tuple(x.shape[:-1]))
+        N.check(N.lib().vb_layernorm_fwd_mx(
+            N.stream_ptr(), rows, cols, N.dev_f32(x, "layernorm input"), N.dev_f32(x2, "layernorm x2"),
+            N.dev_f32(gamma, "layernorm weight"), N.dev_f32(beta, "layernorm bias"), eps, y.data_ptr(), m.q.data_ptr(),
+            cols, m.s.data_ptr(), m.srows), "vb_layernorm_fwd_mx")
+        y._vb_mx = (m, y._version)
+        return y, None, None
     if N.fp8_enabled() and not want_stats and not torch.is_grad_enabled() and cols % FP8_K_MULTIPLE == 0 and x.is_cuda:
         # inference in fp8 mode: the LayerNorm kernel also emits the e4m3 codes of its output rows; the linears that
         # consume this very tensor (same object, not modified since) skip their quantiser pass
