@@ -242,7 +242,7 @@ int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const float* x, i
 
 /* nn.Linear forward on MX operands: v = act(A W^T + bias) (+ residual), A [M][K] and W [N][K] in the format above,
  * K % 128 == 0, N % 128 == 0; a_srows >= M rounded up to 256, w_srows >= N (both % 4 == 0; the kernel fetches the scale
- * words of a 256-row / 128-row tile as one piece). Any subset (at least one) of three outputs of the SAME values v:
+ * words of a 256-row / 128-row tile as one piece). EXACTLY ONE of three output forms of the values v per launch:
  *   C  fp32 [M][N] (ldc floats);  Cb bf16 [M][N] (round to nearest even, ldb16 elements);
  *   Cq + c_scales: v re-quantised to MX along N (the K of the next linear), ldq bytes % 16 == 0, c_srows >= M.
  * act: VB_ACT_NONE or VB_ACT_GELU. No dropout: this is the inference path of BASELINE configs[4]. */
@@ -271,6 +271,32 @@ typedef struct {
 } vb_linear_mx_args;
 
 int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a);
+
+/* Attention of the MX path (csrc/attention_mx.hip): ctx = softmax(Q K^T * scale + mask_add) V per (sample, head) - the
+ * eval-mode arithmetic of BertSelfAttention / BertImageSelfAttention / BertBiAttention (vilbert.py:429-449, 588-608,
+ * 768-809) - on bf16 operands (Q, K, V: bf16 bit patterns, row strides in ELEMENTS % 8 == 0, 16-byte aligned; typically
+ * column slices of the [q | k | v] projection written by vb_linear_fwd_mx's Cb output), bf16 MFMA for both contractions,
+ * fp32 softmax, and the context written in the MX format above for the output projection: Oq [batch * n_q][heads *
+ * head_dim] codes (ldo bytes), o_scales words [heads * head_dim / 128][o_srows]. n_q, n_k <= 48; head_dim 64 or 128;
+ * q_batch / kv_batch = batch or 1 (broadcast); mask_add [kv_batch][n_k] fp32 or NULL. No dropout, no probabilities. */
+typedef struct {
+    int32_t batch, heads, head_dim, n_q, n_k;
+    int32_t q_batch, kv_batch;
+    const uint16_t* Q;
+    int64_t ldq;
+    const uint16_t* K;
+    int64_t ldk;
+    const uint16_t* V;
+    int64_t ldv;
+    const float* mask_add;
+    float scale;
+    uint8_t* Oq;
+    int64_t ldo;
+    uint32_t* o_scales;
+    int64_t o_srows;
+} vb_attention_mx_args;
+
+int vb_attention_fwd_mx(void* stream, const vb_attention_mx_args* a);
 
 /* BertLayerNorm forward (vilbert.py:313-317, as vb_layernorm_fwd: y = LN(x (+ x2))) that ALSO emits every output row in
  * the MX format above for the linears consuming it (n_cols % 128 == 0; scale_rows >= rows). Bit-identical to

@@ -276,3 +276,59 @@ def test_mx_error_of_every_linear_inside_the_model(mx_mode, monkeypatch):
                                                          sorted(r[6] for r in quantised)[len(quantised) // 2], worst[6]) + worst[:6]))
     for M, Nn, K, act, res, kind, err in seen:
         assert err <= 0.06, "linear M=%d N=%d K=%d act=%s residual=%s out=%s: error %.3f of the layer's output" % (M, Nn, K, act, res, kind, err)
+
+
+@pytest.mark.parametrize("B,heads,d,Sq,Sk,qb,kb", [(3, 12, 64, 36, 36, 3, 3), (2, 8, 128, 37, 37, 2, 2), (4, 8, 128, 36, 37, 4, 4),
+                                                    (5, 8, 128, 9, 48, 1, 5), (2, 2, 64, 48, 17, 2, 2), (3, 8, 128, 20, 36, 3, 1)])
+def test_mx_attention_matches_the_float64_statement(B, heads, d, Sq, Sk, qb, kb):
+    """csrc/attention_mx.hip: bf16 q | k | v (column slices of one fused buffer), MX context. Reference: float64 softmax
+    attention of the same bf16 values; the kernel rounds the probabilities to bf16 (2^-9) before P V and the result to
+    e4m3 under a block scale."""
+    from vilbert import ops
+    H = heads * d
+    g_ = torch.Generator().manual_seed(B * 100 + Sq)
+    qkv_q = (torch.randn(qb, Sq, 3 * H, generator=g_) * 0.7).to(torch.bfloat16)
+    qkv_k = (torch.randn(kb, Sk, 3 * H, generator=g_) * 0.7).to(torch.bfloat16)
+    qkv_k[..., 2 * H:] *= torch.exp2(torch.randint(-3, 4, (kb, Sk, 1), generator=g_).float()).to(torch.bfloat16)
+    keep = (torch.rand(kb, Sk, generator=g_) > 0.2).float()
+    keep[:, 0] = 1
+    mask = (1.0 - keep) * -10000.0
+    dq, dk = qkv_q.to(DEV), qkv_k.to(DEV)
+    out = ops.attention_fwd_mx(dq[..., :H], dk[..., H:2 * H], dk[..., 2 * H:], mask.to(DEV), heads)
+    assert out.rows == B * Sq and out.K == H and out.lead == (B, Sq)
+    q = qkv_q[..., :H].double().expand(B, Sq, H).reshape(B, Sq, heads, d).permute(0, 2, 1, 3)
+    k = qkv_k[..., H:2 * H].double().expand(B, Sk, H).reshape(B, Sk, heads, d).permute(0, 2, 1, 3)
+    v = qkv_k[..., 2 * H:].double().expand(B, Sk, H).reshape(B, Sk, heads, d).permute(0, 2, 1, 3)
+    sc = q @ k.transpose(2, 3) / d ** 0.5 + mask.double().expand(B, Sk)[:, None, None, :]
+    want = (torch.softmax(sc, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * Sq, H).numpy()
+    got_b = F.mx_words_to_bytes(_words(out), B * Sq)
+    got = F.mx_dequantize(out.q.cpu().numpy(), got_b)
+    scale = np.ldexp(1.0, got_b.astype(np.int32) - 127).repeat(32, axis=1)
+    vmax = v.abs().amax().item()
+    err = np.abs(got - want)
+    assert np.isfinite(got).all()
+    assert (err <= np.abs(want) / 16 + scale / 1024 * 1.01 + 0.01 * vmax).all(), float((err - np.abs(want) / 16).max())
+    want_b = F.mx_scale_bytes(np.abs(want.astype(np.float32)).reshape(B * Sq, H // 32, 32).max(axis=2))
+    diff = np.abs(want_b.astype(np.int32) - got_b.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.05, (diff.max(), (diff > 0).mean())
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print("mx attention B=%d h=%d d=%d %dx%d: relative L2 error of the MX context %.4f" % (B, heads, d, Sq, Sk, rel))
+    assert rel <= 0.04
+
+
+def test_mx_model_uses_the_bf16_attention_and_keeps_contexts_in_mx(mx_mode, monkeypatch):
+    from vilbert import ops
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    case = "base_2l2c_b8"
+    cfg, sd, x = cases.case_inputs(case)
+    m = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    m.load_state_dict(sd)
+    m = m.eval().to(DEV)
+    calls = {"mx": 0, "f32": 0}
+    real_mx, real_f32 = ops.attention_fwd_mx, ops.attention_fwd
+    monkeypatch.setattr(ops, "attention_fwd_mx", lambda *a, **k: (calls.__setitem__("mx", calls["mx"] + 1), real_mx(*a, **k))[1])
+    monkeypatch.setattr(ops, "attention_fwd", lambda *a, **k: (calls.__setitem__("f32", calls["f32"] + 1), real_f32(*a, **k))[1])
+    with torch.no_grad():
+        m(*helpers.to_device(cases.forward_args(case, x), DEV))
+    # 2 text layers + 2 image layers... every self-attention and both directions of every connection layer
+    assert calls["f32"] == 0 and calls["mx"] >= 6, calls

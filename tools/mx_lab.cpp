@@ -182,8 +182,10 @@ static int check_case(int M, int N, int K) {
     g.W = qW; g.ldw = K; g.w_scales = sW; g.w_srows = w_srows;
     g.M = M; g.N = N; g.K = K;
     // (1) fp32 + bf16 output, bias + residual
-    g.bias = dbias; g.residual = dR; g.ldr = N; g.C = dC; g.ldc = N; g.Cb = dCb; g.ldb16 = N; g.act = VB_ACT_NONE;
+    g.bias = dbias; g.residual = dR; g.ldr = N; g.C = dC; g.ldc = N; g.act = VB_ACT_NONE;
     CK(hipMemset(dC, 0xff, (size_t)M * N * 4));
+    VB(vb_linear_fwd_mx(nullptr, &g));
+    g.C = nullptr; g.Cb = dCb; g.ldb16 = N;       // one output form per launch
     VB(vb_linear_fwd_mx(nullptr, &g));
     CK(hipDeviceSynchronize());
     {
@@ -306,6 +308,10 @@ int main(int argc, char** argv) {
         bad += check_case(9216, 768, 256);       // 216 tiles: more than 256 CUs' worth with N = 768? (36 x 6)
         bad += check_case(4096, 3072, 128);      // 384 tiles: two rounds, 4 x 8 patches
         printf(bad ? "CHECK FAILED (%d)\n" : "CHECK OK\n", bad);
+    }
+    if (what == "order") {     // the same two launches alternately: order / clock effects of the harness
+        for (int rep = 0; rep < 3; ++rep) { time_case(18432, 3072, 768, 0); time_case(18432, 3072, 768, 2); time_case(18432, 3072, 768, 3); }
+        return 0;
     }
     if (what == "time" || what == "all") {
         const int M = 18432;

@@ -1,8 +1,8 @@
 # round-4 GPU call 3: MX path tests + forward A/B (row-scaled fp8 vs MX) + kernel statistics of the MX forward
 mkdir -p gpurun_out
-( timeout 900 python -m pytest tests/test_mx_gpu.py tests/test_fp8_gpu.py -q -x 2>&1 | tail -30 ) > gpurun_out/r04_mx_tests_a.txt
+( timeout 900 python -m pytest tests/test_mx_gpu.py -q 2>&1 | tail -30 ) > gpurun_out/r04_mx_tests_a.txt
 F="python bench.py --mode fwd --batch 512 --steps 10 --warmup 3 --no-alt-mode --no-cpu-baseline --no-extra-legs"
-for m in fp8 mxfp8; do
+for m in mxfp8; do
   ( timeout 300 $F --gemm-mode $m 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$m', d['value'], d['ms_per_step'])" ) >> gpurun_out/r04_fwd_b512_fp8_vs_mx.txt 2>&1
 done
 cd /tmp && export TMPDIR=/tmp

@@ -106,6 +106,8 @@ struct MxP {
     unsigned short* Cb; long ldb16;     // bf16 output (round-to-nearest-even), may be null
     int act;
     int tiles_n, tiles;
+    int flags;   // laboratory build only (VB_MX_FLAGS): 1 = the loaders issue no DMA, 2 = no MFMAs, 4 = no fragment reads,
+                 // 8 = no global stores in the epilogue, 16 = no epilogue at all
 };
 
 // tile of block `b` in round `it` (gemm_v4.h: v4_tile_of / v4_tile_rc): the 32 blocks of an XCD (b % 8) work on a 4 x 8
@@ -146,7 +148,10 @@ template <int N>
 __device__ __forceinline__ void mx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Loader wave of one operand: ND code DMAs (8 rows each) + 1 scale DMA per K tile.
-template <int ND, bool IS_A>
+// PERM (W operand of the fp32 / bf16 launches): LDS row 64 w + 32 j + k of the tile holds W row 64 w + 2 k + j - MFMA tile j of
+// wave column w then multiplies the even (j = 0) / odd (j = 1) columns, so that lane k of the natural accumulator map owns
+// the ADJACENT output columns 2 k, 2 k + 1: 8-byte fp32 / 4-byte bf16 stores, 256 / 128 contiguous bytes per row.
+template <int ND, bool IS_A, bool PERM>
 __device__ __forceinline__ void mx_loader(const MxP& p, const unsigned lds0, const int lane, const int nk, const int rounds) {
     const unsigned char* const mat = IS_A ? p.A : p.B;
     const long ld = IS_A ? p.lda : p.ldb;
@@ -170,17 +175,28 @@ __device__ __forceinline__ void mx_loader(const MxP& p, const unsigned lds0, con
         sbase = sc + r0;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int row = 8 * i + (lane >> 3), slot = lane & 7;
+            const int row = 8 * i + (lane >> 3), slot = lane & 7;     // LDS row of this lane's 16 bytes
             const int chunk = slot ^ ((row >> 1) & 7);
-            off[i] = (unsigned)((long)min(row, nrows - 1 - r0) * ld + 16 * chunk);   // rows past the matrix: clamped, never stored
+#ifdef VB_GEMM_LAB
+            const bool perm = PERM != ((p.flags & 64) != 0);      // lab: flip the row map (timing only, results garbage)
+#else
+            constexpr bool perm = PERM;
+#endif
+            const int grow = perm ? (row & 64) + 2 * (row & 31) + ((row >> 5) & 1) : row;   // matrix row it holds
+            off[i] = (unsigned)((long)min(grow, nrows - 1 - r0) * ld + 16 * chunk);          // rows past the matrix: clamped, never stored
         }
     };
     int it = 0, kt = 0, stage_w = 0;
     auto issue_next = [&]() {
         const unsigned l = lds0 + (unsigned)stage_w * MX_STAGE;
+#ifdef VB_GEMM_LAB
+        if (!(p.flags & 1))
+#endif
+        {
 #pragma unroll
-        for (int i = 0; i < ND; ++i) mx_glds16(off[i], base, l + REG + 1024u * i);
-        mx_glds16(soff, sbase, l + SREG);
+            for (int i = 0; i < ND; ++i) mx_glds16(off[i], base, l + REG + 1024u * i);
+            mx_glds16(soff, sbase, l + SREG);
+        }
         base += MX_BK;
         sbase += sc_rows;
         stage_w = stage_w == MX_S - 1 ? 0 : stage_w + 1;
@@ -194,7 +210,7 @@ __device__ __forceinline__ void mx_loader(const MxP& p, const unsigned lds0, con
     set_tile(0);
     __builtin_amdgcn_s_setprio(2);
     for (int s = 0; s < MX_S && s < total; ++s) issue_next();
-    if (total >= 2) mx_wait_vm<NI>(); else mx_wait_vm<0>();     // K tile 0 has landed (at most the newest one is pending... )
+    if (total >= 2) mx_wait_vm<NI>(); else mx_wait_vm<0>();     // K tile 0 has landed (at most the newest tile is pending)
     __builtin_amdgcn_s_barrier();                                 // P0
     for (int g = 0; g < total; ++g) {
         // K tile g + 1 has landed: issued so far = min(total, g + 3) tiles, so at most tile g + 2 may be pending
@@ -209,7 +225,20 @@ __device__ __forceinline__ unsigned short bf16_rne(float v) {
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// KIND: what the launch writes = how the MFMA product is oriented = who owns what in the epilogue.
+//   MX_OUT_F32 / MX_OUT_BF16: natural product (accumulator rows = output rows in registers, lane & 31 = output column) on a
+//       column-permuted W tile (mx_loader PERM): lane k owns columns 2 k, 2 k + 1 of its wave's 64 and 16 rows per MFMA tile
+//       row - one 8-byte (fp32) / 4-byte (bf16) store per row, 256 / 128 contiguous bytes per row and instruction;
+//   MX_OUT_MX: transposed product (see the head of the file): lane (l31, hi) owns 32-column pieces of ONE row - the block
+//       maximum is 16 in-lane values + one exchange with lane ^ 32.
+// GELU / HAS_R are compile-time too: runtime checks per element (and per-element predication of the 64 stores of a lane)
+// made the epilogue the longest phase of a launch (tools/mx_lab_dbg VB_MX_FLAGS=15 vs 23: 57 us of a 140 us launch spent
+// in an epilogue that stored nothing).
+enum { MX_OUT_F32 = 0, MX_OUT_BF16 = 1, MX_OUT_MX = 2 };
+
+template <int KIND, bool GELU, bool HAS_R>
 __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
+    constexpr bool TRANS = KIND == MX_OUT_MX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nk = p.K / MX_BK;
     const int b = blockIdx.x, grid = gridDim.x;
@@ -219,15 +248,18 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= MX_MFMA_WAVES) {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-        if (wave == MX_MFMA_WAVES) mx_loader<MX_A / 1024, true>(p, lds0, threadIdx.x & 63, nk, rounds);
-        else mx_loader<MX_B / 1024, false>(p, lds0, threadIdx.x & 63, nk, rounds);
+        if (wave == MX_MFMA_WAVES) mx_loader<MX_A / 1024, true, false>(p, lds0, threadIdx.x & 63, nk, rounds);
+        else mx_loader<MX_B / 1024, false, !TRANS>(p, lds0, threadIdx.x & 63, nk, rounds);
         return;
     }
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int key = (l31 >> 1) & 7;
     const int fa_off = (wm * 64 + l31) * MX_BK, fb_off = MX_A + (wn * 64 + l31) * MX_BK;
-    const int sa_off = MX_A + MX_B + 4 * (wm * 64 + l31), sb_off = MX_A + MX_B + MX_SA + 4 * (wn * 64 + l31);
+    const int sa_off = MX_A + MX_B + 4 * (wm * 64 + l31);
+    // scale word of the W row behind LDS row wn 64 + 32 j + l31 (PERM: matrix row wn 64 + 2 l31 + j); + sb_step per j
+    const int sb_off = MX_A + MX_B + MX_SA + 4 * (wn * 64 + (TRANS ? l31 : 2 * l31));
+    constexpr int sb_step = TRANS ? 128 : 4;
 
     f32x16 acc[2][2];
     v8i fa[2][2], fb[2][2];          // [register set = sub-step][tile]
@@ -246,6 +278,9 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
     };
     auto read_set = [&](auto S_, const char* stage) {
         constexpr int S = decltype(S_)::value;
+#ifdef VB_GEMM_LAB
+        if (p.flags & 4) return;
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[S][i] = frag(stage + fa_off + i * 32 * MX_BK, S);
 #pragma unroll
@@ -255,13 +290,16 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const unsigned*>(stage + sa_off + 128 * i);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bq[j] = *reinterpret_cast<const unsigned*>(stage + sb_off + 128 * j);
+        for (int j = 0; j < 2; ++j) bq[j] = *reinterpret_cast<const unsigned*>(stage + sb_off + sb_step * j);
     };
-    // the lane's scale byte for sub-step S (its 32 K elements are block 2 S + hi of the K tile), in all four byte lanes
-    // of the scale operand (whatever byte the instruction's op_sel picks, it is this one)
+    // the lane's scale byte for sub-step S (block 2 S + hi of the K tile), in all four byte lanes of the scale operand
+    // (whatever byte the instruction's op_sel picks, it is this one)
     auto sval = [&](unsigned word, int S) -> int { return (int)(((word >> (8 * (2 * S + hi))) & 0xffu) * 0x01010101u); };
     auto mfmas = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
+#ifdef VB_GEMM_LAB
+        if (p.flags & 2) return;
+#endif
         int va[2], vb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) va[i] = sval(sca[i], S);
@@ -271,10 +309,20 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                // transposed product: first operand = W fragment (its rows -> accumulator registers), second = A fragment
-                // (its rows -> lane & 31); formats 0 / 0 = e4m3 x e4m3
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[S][j], fa[S][i], acc[i][j], 0, 0, 0, vb[j], 0,
-                                                                           va[i]);
+                // formats 0 / 0 = e4m3 x e4m3. Transposed product: first operand = W fragment (its rows -> accumulator
+                // registers), second = A fragment (its rows -> lane & 31); natural: the other way round
+#ifdef VB_GEMM_LAB
+                if (p.flags & 32)      // lab: the other operand order (timing only)
+                    acc[i][j] = !TRANS ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[S][j], fa[S][i], acc[i][j], 0, 0, 0, vb[j],
+                                                                                        0, va[i])
+                                       : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0, va[i],
+                                                                                        0, vb[j]);
+                else
+#endif
+                acc[i][j] = TRANS ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[S][j], fa[S][i], acc[i][j], 0, 0, 0, vb[j],
+                                                                                   0, va[i])
+                                  : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0, va[i],
+                                                                                   0, vb[j]);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -321,79 +369,153 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             mfmas(I1{});
         }
-        // ---- epilogue: lane (l31, hi) holds row m of tile (i, j) and its columns 8 q + 4 hi + e, e = 0..3, in acc[i][j][4 q + e]
         int m0 = 0, n0 = 0;
         mx_origin(p, b, it, grid, m0, n0);
         const int nw = n0 + wn * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nb = nw + 32 * j;            // first column of the 32-column block
-            f32x4 bv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias != nullptr) bv[q] = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hi);
-            }
+#ifdef VB_GEMM_LAB
+        if (p.flags & 16) continue;
+        const bool lab_store = !(p.flags & 8);
+#else
+        constexpr bool lab_store = true;
+#endif
+        if (!TRANS) {
+            // ---- natural map: acc[i][j][r] = row m0 + wm 64 + 32 i + 4 hi + (r & 3) + 8 (r >> 2), column nw + 2 l31 + j
+            const int col = nw + 2 * l31;
+            float2 bv = float2{0.f, 0.f};
+            if (p.bias != nullptr) bv = *reinterpret_cast<const float2*>(p.bias + col);
+            const bool full = m0 + MX_BM <= p.M;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int m = m0 + wm * 64 + 32 * i + l31;
-                const bool live = m < p.M;
-                const long mr = live ? m : p.M - 1;
+                const int rbase = m0 + wm * 64 + 32 * i + 4 * hi;
+                float2 rv[16];
+                if (HAS_R) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)   // clamped, never predicated (a per-element branch serialises the loads)
+                        rv[r] = *reinterpret_cast<const float2*>(p.R + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col);
+                }
+                float2 v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = float2{acc[i][0][r] + bv.x, acc[i][1][r] + bv.y};
+                    if (GELU) v[r] = float2{gelu_erf(v[r].x), gelu_erf(v[r].y)};
+                    if (HAS_R) v[r] = float2{v[r].x + rv[r].x, v[r].y + rv[r].y};
+                }
+                if (KIND == MX_OUT_F32) {
+                    float* __restrict__ cp = p.C + (long)rbase * p.ldc + col;
+                    if (full && lab_store) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) *reinterpret_cast<float2*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc) = v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (rbase + (r & 3) + 8 * (r >> 2) < p.M && (lab_store || v[r].x == 1234.5678f))
+                                *reinterpret_cast<float2*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc) = v[r];
+                    }
+                } else {
+                    unsigned short* __restrict__ cp = p.Cb + (long)rbase * p.ldb16 + col;
+                    if (full && lab_store) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            *reinterpret_cast<unsigned*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldb16) =
+                                (unsigned)bf16_rne(v[r].x) | ((unsigned)bf16_rne(v[r].y) << 16);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (rbase + (r & 3) + 8 * (r >> 2) < p.M && (lab_store || v[r].x == 1234.5678f))
+                                *reinterpret_cast<unsigned*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldb16) =
+                                    (unsigned)bf16_rne(v[r].x) | ((unsigned)bf16_rne(v[r].y) << 16);
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- transposed map (MX output): lane (l31, hi) holds row m of tile (i, j) and its columns 8 q + 4 hi + e, e = 0..3,
+        // in acc[i][j][4 q + e]
+        f32x4 bv[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bv[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias != nullptr) bv[j][q] = *reinterpret_cast<const f32x4*>(p.bias + nw + 32 * j + 8 * q + 4 * hi);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + 32 * i + l31;
+            const bool live = m < p.M;
+            const long mr = live ? m : p.M - 1;
+            v4i piece[2];        // per 32-column block j: this lane's 16 codes (columns 16 hi .. 16 hi + 15 of the block)
+            unsigned bytes = 0;  // scale bytes of blocks j = 0, 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nb = nw + 32 * j;
                 f32x4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[q][e] = acc[i][j][4 * q + e] + bv[q][e];
+                    for (int e = 0; e < 4; ++e) v[q][e] = acc[i][j][4 * q + e] + bv[j][q][e];
                 }
-                if (p.act == VB_ACT_GELU) {
+                if (GELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[q][e] = gelu_erf(v[q][e]);
                 }
-                if (p.R != nullptr) {
+                if (HAS_R) {
                     f32x4 rv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(p.R + mr * p.ldr + nb + 8 * q + 4 * hi);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] += rv[q];
                 }
-                if (p.C != nullptr && live) {
+                // the row's 32-column block = this lane's 16 values + lane ^ 32's 16
+                float amax = fmaxf(fmaxf(amax4(v[0]), amax4(v[1])), fmaxf(amax4(v[2]), amax4(v[3])));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                const unsigned byte = mx_scale_byte(amax);
+                const float inv = mx_inv_scale(byte);
+                bytes |= byte << (8 * j);
+                unsigned d[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + nb + 8 * q + 4 * hi) = v[q];
-                }
-                if (p.Cb != nullptr && live) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned w0 = (unsigned)bf16_rne(v[q][0]) | ((unsigned)bf16_rne(v[q][1]) << 16);
-                        const unsigned w1 = (unsigned)bf16_rne(v[q][2]) | ((unsigned)bf16_rne(v[q][3]) << 16);
-                        *reinterpret_cast<uint2*>(p.Cb + (long)m * p.ldb16 + nb + 8 * q + 4 * hi) = uint2{w0, w1};
-                    }
-                }
-                if (p.Cq != nullptr) {
-                    // the row's 32-column block = this lane's 16 values + lane ^ 32's 16
-                    float amax = fmaxf(fmaxf(amax4(v[0]), amax4(v[1])), fmaxf(amax4(v[2]), amax4(v[3])));
-                    amax = fmaxf(amax, __shfl_xor(amax, 32));
-                    const unsigned byte = mx_scale_byte(amax);
-                    const float inv = mx_inv_scale(byte);
-                    unsigned d[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) d[q] = mx_pack4(v[q], inv);
-                    // lane hi = 0 holds columns {0-3, 8-11, 16-19, 24-27}, its partner {4-7, 12-15, 20-23, 28-31}: after the
-                    // exchange hi = 0 owns columns 0-15 and hi = 1 columns 16-31 (one 16-byte store each)
-                    const unsigned x = (unsigned)__shfl_xor((int)(hi ? d[0] : d[2]), 32);
-                    const unsigned y = (unsigned)__shfl_xor((int)(hi ? d[1] : d[3]), 32);
-                    const v4i out = hi ? v4i{(int)x, (int)d[2], (int)y, (int)d[3]} : v4i{(int)d[0], (int)x, (int)d[1], (int)y};
-                    if (live) {
-                        *reinterpret_cast<v4i*>(p.Cq + (long)m * p.ldq + nb + 16 * hi) = out;
-                        // scale byte of (row m, block nb / 32): byte (nb / 32) % 4 of word (nb / 128, m)
-                        if (hi == 0)
-                            reinterpret_cast<unsigned char*>(p.cs + (long)(nb >> 7) * p.cs_rows + m)[(nb >> 5) & 3] = (unsigned char)byte;
-                    }
-                }
+                for (int q = 0; q < 4; ++q) d[q] = mx_pack4(v[q], inv);
+                // lane hi = 0 holds columns {0-3, 8-11, 16-19, 24-27}, its partner {4-7, 12-15, 20-23, 28-31}: after the
+                // exchange hi = 0 owns columns 0-15 and hi = 1 columns 16-31 of the block
+                const unsigned x = (unsigned)__shfl_xor((int)(hi ? d[0] : d[2]), 32);
+                const unsigned y = (unsigned)__shfl_xor((int)(hi ? d[1] : d[3]), 32);
+                piece[j] = hi ? v4i{(int)x, (int)d[2], (int)y, (int)d[3]} : v4i{(int)d[0], (int)x, (int)d[1], (int)y};
             }
+            // Full 64-byte segments: rows of 16 lanes trade pieces (v_permlane16_swap: odd 16-lane rows of the first operand
+            // <-> even rows of the second) so that the first store covers tile rows 0-15 (lanes 0-15 / 32-47: block 0, lanes
+            // 16-31 / 48-63: block 1 of row lane & 15) and the second rows 16-31 - 4 lanes x 16 bytes per output row and
+            // instruction instead of 2.
+            v4i st0, st1;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)piece[0][w], (unsigned)piece[1][w], false, false);
+                st0[w] = (int)sw[0];
+                st1[w] = (int)sw[1];
+            }
+            {
+                const int blk = (l31 >> 4) & 1, rr = l31 & 15;
+                const int mA = m0 + wm * 64 + 32 * i + rr, mB = mA + 16;
+                if (mA < p.M && (lab_store || st0[0] == 0x12345678)) *reinterpret_cast<v4i*>(p.Cq + (long)mA * p.ldq + nw + 32 * blk + 16 * hi) = st0;
+                if (mB < p.M && (lab_store || st1[0] == 0x12345678)) *reinterpret_cast<v4i*>(p.Cq + (long)mB * p.ldq + nw + 32 * blk + 16 * hi) = st1;
+            }
+            // scale bytes of (row m, blocks nw / 32 and nw / 32 + 1): bytes 2 wn, 2 wn + 1 of word (n0 / 128, m)
+            if (live && hi == 0)
+                reinterpret_cast<unsigned short*>(p.cs + (long)(n0 >> 7) * p.cs_rows + m)[wn] = (unsigned short)bytes;
         }
     }
+}
+
+template <int KIND, bool GELU, bool HAS_R>
+int launch_mx(hipStream_t st, const MxP& p) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<KIND, GELU, HAS_R>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    const int grid = p.tiles < 256 ? p.tiles : 256;
+    hipLaunchKernelGGL((gemm_mx_kernel<KIND, GELU, HAS_R>), dim3(grid), dim3(MX_THREADS), MX_LDS, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -422,7 +544,8 @@ extern "C" int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const 
 extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {
     if (a == nullptr || a->A == nullptr || a->W == nullptr || a->a_scales == nullptr || a->w_scales == nullptr)
         return VB_E_BADARG;
-    if (a->C == nullptr && a->Cq == nullptr && a->Cb == nullptr) return VB_E_BADARG;
+    // exactly one output form per launch
+    if ((a->C != nullptr) + (a->Cq != nullptr) + (a->Cb != nullptr) != 1) return VB_E_BADARG;
     if (a->Cq != nullptr && a->c_scales == nullptr) return VB_E_BADARG;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) return VB_E_BADARG;
     if (a->act != VB_ACT_NONE && a->act != VB_ACT_GELU) return VB_E_BADARG;
@@ -437,6 +560,7 @@ extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {
     if (a->Cq != nullptr && (a->ldq % 16 != 0 || a->ldq < a->N || !vb_aligned16(a->Cq) || a->c_srows < a->M)) return VB_E_ALIGN;
     if (a->residual != nullptr && (a->ldr % 4 != 0 || a->ldr < a->N || !vb_aligned16(a->residual))) return VB_E_ALIGN;
     if (a->bias != nullptr && !vb_aligned16(a->bias)) return VB_E_ALIGN;
+    if (a->residual != nullptr && a->ldr % 2 != 0) return VB_E_ALIGN;
     if ((long)a->M * a->lda > 0xffffffffL && a->lda * 256 > 0xffffffffL) return VB_E_RANGE;
     MxP p{};
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
@@ -449,11 +573,20 @@ extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {
     p.act = a->act;
     p.tiles_n = p.N / MX_BN;
     p.tiles = ((p.M + MX_BM - 1) / MX_BM) * p.tiles_n;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
-    if (attr != hipSuccess) return (int)attr;
-    const int grid = p.tiles < 256 ? p.tiles : 256;
-    hipLaunchKernelGGL(gemm_mx_kernel, dim3(grid), dim3(MX_THREADS), MX_LDS, static_cast<hipStream_t>(stream), p);
-    VB_LAUNCH_CHECK();
-    return 0;
+#ifdef VB_GEMM_LAB
+    static const int flags = [] { const char* e = getenv("VB_MX_FLAGS"); return e ? atoi(e) : 0; }();
+    p.flags = flags;
+#endif
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool gelu = a->act == VB_ACT_GELU, res = a->residual != nullptr;
+    if (p.Cq != nullptr) {
+        if (res) return gelu ? launch_mx<MX_OUT_MX, true, true>(st, p) : launch_mx<MX_OUT_MX, false, true>(st, p);
+        return gelu ? launch_mx<MX_OUT_MX, true, false>(st, p) : launch_mx<MX_OUT_MX, false, false>(st, p);
+    }
+    if (p.Cb != nullptr) {
+        if (res) return gelu ? launch_mx<MX_OUT_BF16, true, true>(st, p) : launch_mx<MX_OUT_BF16, false, true>(st, p);
+        return gelu ? launch_mx<MX_OUT_BF16, true, false>(st, p) : launch_mx<MX_OUT_BF16, false, false>(st, p);
+    }
+    if (res) return gelu ? launch_mx<MX_OUT_F32, true, true>(st, p) : launch_mx<MX_OUT_F32, false, true>(st, p);
+    return gelu ? launch_mx<MX_OUT_F32, true, false>(st, p) : launch_mx<MX_OUT_F32, false, false>(st, p);
 }

@@ -75,6 +75,22 @@ class LinearMxArgs(ctypes.Structure):
     ]
 
 
+class AttentionMxArgs(ctypes.Structure):
+    """vb_attention_mx_args"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("heads", ctypes.c_int32), ("head_dim", ctypes.c_int32),
+        ("n_q", ctypes.c_int32), ("n_k", ctypes.c_int32),
+        ("q_batch", ctypes.c_int32), ("kv_batch", ctypes.c_int32),
+        ("Q", ctypes.c_void_p), ("ldq", ctypes.c_int64),
+        ("K", ctypes.c_void_p), ("ldk", ctypes.c_int64),
+        ("V", ctypes.c_void_p), ("ldv", ctypes.c_int64),
+        ("mask_add", _c_f32p),
+        ("scale", ctypes.c_float),
+        ("Oq", ctypes.c_void_p), ("ldo", ctypes.c_int64),
+        ("o_scales", ctypes.c_void_p), ("o_srows", ctypes.c_int64),
+    ]
+
+
 class AttentionArgs(ctypes.Structure):
     """vb_attention_args"""
     _fields_ = [
@@ -177,6 +193,7 @@ SIGNATURES = {
     "vb_quantize_rows_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _I64]),
     "vb_linear_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(LinearMxArgs)]),
     "vb_layernorm_fwd_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P, _I64]),
+    "vb_attention_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(AttentionMxArgs)]),
     "vb_act_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "vb_dropout": (ctypes.c_int, [_P, _I64, _P, _P, _P, _F32, _U64]),
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),

@@ -14,9 +14,10 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def linear(x, weights, biases=None, act=None, residual=None, drop_p=0.0, pad_cols=False):
+def linear(x, weights, biases=None, act=None, residual=None, drop_p=0.0, pad_cols=False, out="f32"):
     """dropout(act(x @ cat(weights).T + cat(biases)), drop_p) (+ residual); weights / biases may be single
-    tensors; drop_p is the EFFECTIVE probability (0 in eval mode). pad_cols: see ops.linear_fwd."""
+    tensors; drop_p is the EFFECTIVE probability (0 in eval mode). pad_cols, out: see ops.linear_fwd (out is a request
+    the MX inference mode honours where the shape allows it; everywhere else the result is an fp32 tensor)."""
     if not isinstance(weights, (list, tuple)):
         weights, biases = [weights], [biases]
     if biases is None:
@@ -24,7 +25,7 @@ def linear(x, weights, biases=None, act=None, residual=None, drop_p=0.0, pad_col
     if _needs_grad(x, residual, *weights, *biases):
         return A.LinearFn.apply(x, residual, act, -len(weights) if pad_cols else len(weights), drop_p, *weights, *biases)
     seed = A.next_seed() if drop_p > 0.0 else 0
-    return ops.linear_fwd(x, weights, biases, act, residual, drop_p=drop_p, seed=seed, pad_cols=pad_cols)[0]
+    return ops.linear_fwd(x, weights, biases, act, residual, drop_p=drop_p, seed=seed, pad_cols=pad_cols, out=out)[0]
 
 
 def ffn(x, w1, b1, act, w2, b2, drop_p=0.0):
@@ -63,6 +64,8 @@ def self_attention(qkv, mask_add, heads, drop_p=0.0, want_probs=False):
         out, probs = A.SelfAttnFn.apply(qkv, mask_add, heads, drop_p, want_probs)
         return out, (probs if want_probs else None)
     H = qkv.shape[-1] // 3
+    if qkv.dtype == torch.bfloat16:     # MX inference mode: bf16 projection in, MX context out (ops.mx_attention_ok held)
+        return ops.attention_fwd_mx(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads), None
     seed = A.next_seed() if drop_p > 0.0 else 0
     out, probs, _ = ops.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads,
                                       want_probs, False, drop_p, seed)
@@ -76,6 +79,10 @@ def bi_attention(qkv1, qkv2, mask1, mask2, heads, p1=0.0, p2=0.0, want_probs=Fal
         c1, c2, pr1, pr2 = A.BiAttnFn.apply(qkv1, qkv2, mask1, mask2, heads, p1, p2, want_probs)
         return c1, c2, (pr1 if want_probs else None), (pr2 if want_probs else None)
     H = qkv1.shape[-1] // 3
+    if qkv1.dtype == torch.bfloat16 and qkv2.dtype == torch.bfloat16:
+        c1 = ops.attention_fwd_mx(qkv2[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:], mask1, heads)
+        c2 = ops.attention_fwd_mx(qkv1[..., :H], qkv2[..., H:2 * H], qkv2[..., 2 * H:], mask2, heads)
+        return c1, c2, None, None
     s1 = A.next_seed() if p1 > 0.0 else 0
     s2 = A.next_seed() if p2 > 0.0 else 0
     c1, pr1, _ = ops.attention_fwd(qkv2[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:], mask1, heads,

@@ -196,6 +196,8 @@ class MxRows(object):
     (kt, r) = the four E8M0 bytes of row r's K range [128 kt, 128 kt + 128)); `lead` = the leading shape of the tensor it
     stands for. Not a torch tensor: only `linear_fwd` consumes it."""
     __slots__ = ("q", "s", "srows", "rows", "K", "lead")
+    requires_grad = False      # (inference only; lets the autograd dispatch of functional.py treat it like a tensor)
+    is_cuda = True
 
     def __init__(self, rows, K, device, lead):
         self.rows, self.K, self.lead = rows, K, tuple(lead)
@@ -206,6 +208,10 @@ class MxRows(object):
     @property
     def shape(self):
         return self.lead + (self.K,)
+
+    @property
+    def device(self):
+        return self.q.device
 
 
 def quantize_rows_mx(x2, lead=None, out=None):
@@ -703,6 +709,45 @@ def attention_fwd(q, k, v, mask_add, heads, want_probs=False, want_lse=False, dr
     a.lse = lse.data_ptr() if want_lse else None
     N.check(N.lib().vb_attention_fwd(N.stream_ptr(), ctypes.byref(a)), "vb_attention_fwd")
     return out, probs, lse
+
+
+MX_ATTN_MAX_ROWS = 48
+
+
+def mx_attention_ok(n_q, n_k, head_dim, drop_p=0.0, other=False):
+    """The MX path's attention kernel (csrc/attention_mx.hip: bf16 q | k | v in, MX context out) serves this call."""
+    return (N.mx_enabled() and not torch.is_grad_enabled() and n_q <= MX_ATTN_MAX_ROWS and n_k <= MX_ATTN_MAX_ROWS
+            and head_dim in (64, 128) and drop_p == 0.0 and not other)
+
+
+def attention_fwd_mx(q, k, v, mask_add, heads):
+    """q [Bq, Sq, H], k / v [Bk, Sk, H]: bfloat16 row-strided views (column slices of a fused projection); returns the
+    context [B, Sq, H] as MxRows (the codes the output projection consumes)."""
+    Bq, Sq, H = q.shape
+    Bk, Sk, _ = k.shape
+    B = max(Bq, Bk)
+    d = H // heads
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dtype != torch.bfloat16 or not t.is_cuda:
+            raise RuntimeError("attention (mx): %s must be a bfloat16 tensor on a HIP device" % nm)
+        if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)):
+            raise RuntimeError("attention (mx): %s must be a row-strided view" % nm)
+    a = N.AttentionMxArgs()
+    a.batch, a.heads, a.head_dim, a.n_q, a.n_k = B, heads, d, Sq, Sk
+    a.q_batch, a.kv_batch = Bq, Bk
+    a.Q, a.ldq = q.data_ptr(), q.stride(1)
+    a.K, a.ldk = k.data_ptr(), k.stride(1)
+    a.V, a.ldv = v.data_ptr(), v.stride(1)
+    if mask_add is not None:
+        mask_add = _contig(mask_add)
+        if mask_add.numel() != Bk * Sk:
+            raise RuntimeError("attention: mask must hold %d x %d values" % (Bk, Sk))
+        a.mask_add = N.dev_f32(mask_add, "attention mask")
+    a.scale = 1.0 / math.sqrt(d)
+    out = MxRows(B * Sq, H, q.device, (B, Sq))
+    a.Oq, a.ldo, a.o_scales, a.o_srows = out.q.data_ptr(), H, out.s.data_ptr(), out.srows
+    N.check(N.lib().vb_attention_fwd_mx(N.stream_ptr(), ctypes.byref(a)), "vb_attention_fwd_mx")
+    return out
 
 
 def attention_bwd(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p=0.0, seed=0):

@@ -25,6 +25,7 @@ from torch.nn import CrossEntropyLoss
 import torch.nn.functional as TF
 
 from . import functional as F
+from . import ops
 from .utils import PreTrainedModel
 
 logger = logging.getLogger(__name__)
@@ -122,9 +123,17 @@ def _concurrent(side_fn, main_fn, side_inputs, enabled=True):
     side = _side_stream(t0.device)
     side.wait_stream(main)
     def _record(t, stream):
+        if isinstance(t, ops.MxRows):                   # a result that exists only as MX codes + scale words
+            t.q.record_stream(stream)
+            t.s.record_stream(stream)
+            return
         t.record_stream(stream)
         for extra in getattr(t, "_vb_fp8", ())[:2]:     # e4m3 codes + scales riding on a LayerNorm output (ops.py)
             extra.record_stream(stream)
+        mx = getattr(t, "_vb_mx", None)                 # the same in the MX mode
+        if mx is not None:
+            mx[0].q.record_stream(stream)
+            mx[0].s.record_stream(stream)
 
     for t in side_inputs:
         _record(t, side)            # allocated on `main`, consumed by kernels on `side`
@@ -133,7 +142,7 @@ def _concurrent(side_fn, main_fn, side_inputs, enabled=True):
     b = main_fn()
     main.wait_stream(side)
     for t in (a if isinstance(a, (tuple, list)) else (a,)):
-        if torch.is_tensor(t):
+        if torch.is_tensor(t) or isinstance(t, ops.MxRows):
             _record(t, main)        # allocated on `side`, consumed from here on by kernels on `main`
     return a, b
 
@@ -224,8 +233,11 @@ class RobertaEmbeddings(BertEmbeddings):
 def _self_attention(mod, hidden_states, attention_mask, gates=None):
     """Shared body of BertSelfAttention / BertImageSelfAttention: fused q|k|v GEMM + attention kernel."""
     H = mod.all_head_size
+    # MX inference mode: the projection leaves its GEMM as bf16 and the attention kernel returns the context as MX codes
+    S = hidden_states.shape[1] if hidden_states.dim() == 3 else 10 ** 9
+    to_mx = ops.mx_attention_ok(S, S, mod.attention_head_size, _drop_p(mod.dropout), mod.visualization or gates is not None)
     qkv = F.linear(hidden_states, [mod.query.weight, mod.key.weight, mod.value.weight],
-                   [mod.query.bias, mod.key.bias, mod.value.bias])
+                   [mod.query.bias, mod.key.bias, mod.value.bias], out="bf16" if to_mx else "f32")
     if gates is not None:  # dynamic_attention (:577-586): rare path, small elementwise gates kept in torch
         qkv = torch.cat([qkv[..., :H] * gates[0].unsqueeze(1), qkv[..., H:2 * H] * gates[1].unsqueeze(1),
                          qkv[..., 2 * H:]], dim=-1)
@@ -449,11 +461,16 @@ class BertBiAttention(nn.Module):
     def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
                 use_co_attention_mask=False):
         H = self.all_head_size
+        S1, S2 = input_tensor1.shape[1], input_tensor2.shape[1]
+        to_mx = (ops.mx_attention_ok(max(S1, S2), max(S1, S2), self.attention_head_size,
+                                     max(_drop_p(self.dropout1), _drop_p(self.dropout2)), self.visualization)
+                 and all(ops.mx_eligible(w.shape[1], 3 * w.shape[0]) for w in (self.query1.weight, self.query2.weight)))
+        fmt = "bf16" if to_mx else "f32"
         qkv1, qkv2 = _concurrent(   # the image-side and text-side projections are independent
             lambda: F.linear(input_tensor1, [self.query1.weight, self.key1.weight, self.value1.weight],
-                             [self.query1.bias, self.key1.bias, self.value1.bias]),
+                             [self.query1.bias, self.key1.bias, self.value1.bias], out=fmt),
             lambda: F.linear(input_tensor2, [self.query2.weight, self.key2.weight, self.value2.weight],
-                             [self.query2.bias, self.key2.bias, self.value2.bias]),
+                             [self.query2.bias, self.key2.bias, self.value2.bias], out=fmt),
             [input_tensor1])
         # context_layer1: text queries over image keys / values -> TEXT stream (:768-785, dropout1)
         # context_layer2: image queries over text keys / values -> IMAGE stream (:787-809, dropout2)
