@@ -245,7 +245,8 @@ int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const float* x, i
  * words of a 256-row / 128-row tile as one piece). EXACTLY ONE of three output forms of the values v per launch:
  *   C  fp32 [M][N] (ldc floats);  Cb bf16 [M][N] (round to nearest even, ldb16 elements);
  *   Cq + c_scales: v re-quantised to MX along N (the K of the next linear), ldq bytes % 16 == 0, c_srows >= M.
- * act: VB_ACT_NONE or VB_ACT_GELU. No dropout: this is the inference path of BASELINE configs[4]. */
+ * act: VB_ACT_NONE or VB_ACT_GELU. No dropout: this is the inference path of BASELINE configs[4]. Built combinations:
+ * C / Cb with or without residual (bf16 residual: without GELU), Cq with GELU or with an fp32 residual; others VB_E_BADARG. */
 typedef struct {
     const uint8_t* A;
     int64_t lda;
@@ -258,6 +259,8 @@ typedef struct {
     const float* bias;       /* [N] or NULL */
     const float* residual;   /* fp32 [M][N] or NULL */
     int64_t ldr;
+    const uint16_t* residual_bf16; /* bf16 [M][N] or NULL (at most one of the two residuals) */
+    int64_t ldr16;
     float* C;                /* or NULL */
     int64_t ldc;
     uint16_t* Cb;            /* or NULL */
@@ -271,6 +274,13 @@ typedef struct {
 } vb_linear_mx_args;
 
 int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a);
+
+/* BertLayerNorm forward of the MX path's bf16 residual stream: x bf16 [rows][n_cols] (the pre-LayerNorm sum a
+ * vb_linear_fwd_mx launch wrote through Cb) -> y bf16 (the next residual) AND its MX codes + scale words; statistics in fp32
+ * exactly as vb_layernorm_fwd (vilbert.py:313-317) on the bf16 values. n_cols % 128 == 0. The codes are those of the fp32
+ * result BEFORE it is rounded to bf16. */
+int vb_layernorm_fwd_mx16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* x, const float* gamma, const float* beta,
+                          float eps, uint16_t* y, uint8_t* q, int64_t ldq, uint32_t* scales, int64_t scale_rows);
 
 /* Attention of the MX path (csrc/attention_mx.hip): ctx = softmax(Q K^T * scale + mask_add) V per (sample, head) - the
  * eval-mode arithmetic of BertSelfAttention / BertImageSelfAttention / BertBiAttention (vilbert.py:429-449, 588-608,

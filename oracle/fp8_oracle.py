@@ -143,3 +143,18 @@ def linear_mx(x, w, bias=None):
     if bias is not None:
         y = y + np.asarray(bias, dtype=np.float64)[None, :]
     return y
+
+
+MX_GELU_COEF = (0.398325773, -0.0648922966, 0.00876406186, -0.000774126121, 3.89366778e-05, -8.3218473e-07)
+
+
+def mx_gelu(x):
+    """GELU of the MX GEMM epilogues (csrc/mx8.h mx_gelu): x * (0.5 + t Q(t^2)), t = clamp(x, -3.5, 3.5), Q of degree 5 -
+    within 4e-4 |x| + 6e-4 of the reference's erf form (vilbert.py:111-117), float64 here."""
+    x = np.asarray(x, dtype=np.float64)
+    t = np.clip(x, -3.5, 3.5)
+    u = t * t
+    q = np.zeros_like(u)
+    for c in reversed(MX_GELU_COEF):
+        q = q * u + c
+    return x * (0.5 + t * q)

@@ -33,7 +33,7 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_quantize_rows_mx", "vb_linear_fwd_mx", "vb_layernorm_fwd_mx", "vb_attention_fwd_mx", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
+EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_quantize_rows_mx", "vb_linear_fwd_mx", "vb_layernorm_fwd_mx", "vb_attention_fwd_mx", "vb_layernorm_fwd_mx16", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd"]
 
 

@@ -98,3 +98,10 @@ def test_mx_linear_is_closer_to_fp32_than_its_bound():
     exact = x.astype(np.float64) @ w.astype(np.float64).T
     rel = np.linalg.norm(y - exact) / np.linalg.norm(exact)
     assert 1e-4 < rel < 0.06, rel
+
+
+def test_mx_gelu_polynomial_is_within_its_stated_bound_of_the_erf_form():
+    x = np.linspace(-12, 12, 200001)
+    want = torch.nn.functional.gelu(torch.from_numpy(x)).numpy()
+    err = np.abs(F.mx_gelu(x) - want)
+    assert (err <= 4e-4 * np.abs(x) + 6e-4).all(), float((err - 4e-4 * np.abs(x)).max())

@@ -134,7 +134,7 @@ def test_mx_gemm_emits_the_codes_of_its_result(M, N, K, act):
     # and against the float64 statement: within one e4m3 rounding
     want = F.linear_mx(x.numpy(), w.numpy(), b.numpy())
     if act == "gelu":
-        want = torch.nn.functional.gelu(torch.from_numpy(want)).numpy()
+        want = F.mx_gelu(want)               # the epilogue's polynomial GELU (oracle: within 4e-4 |x| + 6e-4 of the erf form)
     back = F.mx_dequantize(ym.q.cpu().numpy(), got_b)
     scale = np.ldexp(1.0, got_b.astype(np.int32) - 127).repeat(32, axis=1)
     mag = F.mx_dequantize(*F.mx_quantize(x.numpy())).__abs__() @ np.abs(F.mx_dequantize(*F.mx_quantize(w.numpy()))).T + 1.0
@@ -195,7 +195,8 @@ def test_ffn_keeps_its_activation_in_mx(mx_mode, monkeypatch):
         assert kinds == [("Tensor", "MxRows"), ("MxRows", "Tensor")]
         h32, _ = real(x, [w1], [b1], "gelu")
         y_two, _ = real(h32, [w2], [b2], None, x)
-    assert torch.equal(y, y_two)
+    # (the MX mode keeps the residual stream in bf16: the fused call returns the same values rounded to bf16)
+    assert y.dtype == torch.bfloat16 and y_two.dtype == torch.float32 and torch.equal(y, y_two.to(torch.bfloat16))
     want = torch.nn.functional.gelu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double() + x.double()
     assert ((y.double() - want).norm() / want.norm()).item() <= 0.06
 
@@ -248,13 +249,19 @@ def test_mx_error_of_every_linear_inside_the_model(mx_mode, monkeypatch):
                 if isinstance(xin, ops.MxRows) else xin
             y_cmp = torch.from_numpy(F.mx_dequantize(y.q.cpu().numpy(), F.mx_words_to_bytes(_words(y), y.rows))).float().to(DEV) \
                 if isinstance(y, ops.MxRows) else y
+            xin32 = xin32.float() if xin32.dtype == torch.bfloat16 else xin32
             xin32 = xin32.view(-1, xin32.shape[-1])
             kw32 = {k: v for k, v in kw.items() if k != "out"}
         else:
-            xin32, y_cmp, kw32 = xin, y, kw
+            xin32, y_cmp, kw32 = (xin.float() if xin.dtype == torch.bfloat16 else xin), y, kw
         prev = _native.set_gemm_mode("f32")
         try:
-            y32, _ = real(xin32, weights, biases, act, residual.view(-1, residual.shape[-1]) if (residual is not None and xin32 is not xin) else residual, **kw32)
+            res32 = residual
+            if res32 is not None:
+                res32 = res32.float() if res32.dtype == torch.bfloat16 else res32
+                if xin32 is not xin:
+                    res32 = res32.view(-1, res32.shape[-1])
+            y32, _ = real(xin32, weights, biases, act, res32, **kw32)
         finally:
             _native.set_gemm_mode(prev)
         w0 = weights[0] if isinstance(weights, (list, tuple)) else weights
@@ -332,3 +339,36 @@ def test_mx_model_uses_the_bf16_attention_and_keeps_contexts_in_mx(mx_mode, monk
         m(*helpers.to_device(cases.forward_args(case, x), DEV))
     # 2 text layers + 2 image layers... every self-attention and both directions of every connection layer
     assert calls["f32"] == 0 and calls["mx"] >= 6, calls
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 768), (130, 1024)])
+def test_bf16_stream_layernorm_and_residual(mx_mode, rows, cols):
+    """The bf16 residual stream of the MX mode: a GEMM adds a bf16 residual and writes the sum as bf16; the LayerNorm reads it,
+    writes the next residual as bf16 and its MX codes (quantiser of the fp32 result, before the bf16 rounding)."""
+    from vilbert import ops
+    g_ = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cols, generator=g_) * 2).to(torch.bfloat16).to(DEV)
+    g, b = (1 + 0.1 * torch.randn(cols, generator=g_)).to(DEV), (0.1 * torch.randn(cols, generator=g_)).to(DEV)
+    with torch.no_grad():
+        y, _, _ = ops.layernorm_fwd(x, g, b, 1e-12)
+    assert y.dtype == torch.bfloat16 and hasattr(y, "_vb_mx")
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    want = g.double() * (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-12) + b.double()
+    assert (y.double() - want).abs().le(want.abs() / 256 + 1e-5).all()
+    m = y._vb_mx[0]
+    q_ref, b_ref = F.mx_quantize(want.float().cpu().numpy())
+    got_b = F.mx_words_to_bytes(_words(m), rows)
+    assert (np.abs(got_b.astype(np.int32) - b_ref.astype(np.int32)) <= 1).all() and (got_b != b_ref).mean() < 0.01
+    back = F.mx_dequantize(m.q.cpu().numpy(), got_b)
+    scale = np.ldexp(1.0, got_b.astype(np.int32) - 127).repeat(32, axis=1)
+    assert (np.abs(back - want.cpu().numpy()) <= np.abs(want.cpu().numpy()) / 16 + scale / 1024 * 1.01 + 1e-5).all()
+    # GEMM with a bf16 residual, bf16 sum out
+    w = (torch.randn(cols, cols, generator=g_) * 0.03).to(DEV)
+    bias = torch.randn(cols, generator=g_).to(DEV)
+    xin = torch.randn(rows, cols, generator=g_).to(DEV)
+    with torch.no_grad():
+        s16, _ = ops.linear_fwd(xin, [w], [bias], None, y, out="bf16")
+        s32, _ = ops.linear_fwd(xin, [w], [bias], None, y.float())
+    assert s16.dtype == torch.bfloat16 and s32.dtype == torch.float32
+    assert (s16.double() - s32.double()).abs().le(s32.double().abs() / 256 + 1e-6).all()

@@ -83,7 +83,14 @@ static void quant_host(const float* x, long rows, int K, long srows, std::vector
             sc[(size_t)(b / 4) * srows + r] |= byte << (8 * (b % 4));
         }
 }
-static double gelu_ref(double x) { return x * 0.5 * (1.0 + erf(x / sqrt(2.0))); }
+// the epilogue's GELU (csrc/mx8.h mx_gelu): odd polynomial of Phi on the clamped argument
+static double gelu_ref(double x) {
+    static const double c[6] = {0.398325773, -0.0648922966, 0.00876406186, -0.000774126121, 3.89366778e-05, -8.3218473e-07};
+    const double t = std::min(3.5, std::max(-3.5, x)), u = t * t;
+    double q = 0;
+    for (int k = 5; k >= 0; --k) q = q * u + c[k];
+    return x * (0.5 + t * q);
+}
 
 template <class T>
 static T* to_dev(const std::vector<T>& v) {

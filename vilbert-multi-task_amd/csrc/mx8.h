@@ -41,3 +41,19 @@ __device__ __forceinline__ void mx_quant_chunk(const f32x4 v, bool ok, int lane,
     if ((lane & 31) == 0 && kt < nkt) *sword = w;
 }
 
+
+// GELU of the MX epilogues: x Phi(x) with Phi from an odd polynomial of degree 11 on the clamped argument,
+//   Phi(t) ~ 0.5 + t Q(t^2),  t = clamp(x, -3.5, 3.5)     (minimax fit, |Phi error| <= 1.6e-4; restated in oracle/fp8_oracle.py)
+// -> |gelu error| <= 4e-4 |x| + 6e-4: two orders below the e4m3 step (2^-4 relative) the value is rounded to right after.
+// 10 full-rate VALU instructions; the erf form of the fp32 path (common.h gelu_parts: rcp + exp + ~14) made the GELU epilogue
+// of the 3072-wide up-projection VALU-bound (40 us of a 78 us launch at 18,432 rows, tools/mx_lab).
+__device__ __forceinline__ float mx_gelu(float x) {
+    const float t = __builtin_amdgcn_fmed3f(x, -3.5f, 3.5f);
+    const float u = t * t;
+    float q = fmaf(-8.3218473e-07f, u, 3.89366778e-05f);
+    q = fmaf(q, u, -0.000774126121f);
+    q = fmaf(q, u, 0.00876406186f);
+    q = fmaf(q, u, -0.0648922966f);
+    q = fmaf(q, u, 0.398325773f);
+    return x * fmaf(t, q, 0.5f);
+}

@@ -101,6 +101,7 @@ struct MxP {
     const unsigned char* B; long ldb; const unsigned* sb; long sb_rows;
     const float* bias;
     const float* R; long ldr;
+    const unsigned short* R16; long ldr16;   // bf16 residual (the MX inference mode keeps the residual stream in bf16)
     float* C; long ldc;
     unsigned char* Cq; long ldq; unsigned* cs; long cs_rows;
     unsigned short* Cb; long ldb16;     // bf16 output (round-to-nearest-even), may be null
@@ -231,14 +232,16 @@ __device__ __forceinline__ unsigned short bf16_rne(float v) {
 //       row - one 8-byte (fp32) / 4-byte (bf16) store per row, 256 / 128 contiguous bytes per row and instruction;
 //   MX_OUT_MX: transposed product (see the head of the file): lane (l31, hi) owns 32-column pieces of ONE row - the block
 //       maximum is 16 in-lane values + one exchange with lane ^ 32.
-// GELU / HAS_R are compile-time too: runtime checks per element (and per-element predication of the 64 stores of a lane)
+// RES: 0 = no residual, 1 = fp32 residual (R), 2 = bf16 residual (R16).
+// GELU / RES are compile-time too: runtime checks per element (and per-element predication of the 64 stores of a lane)
 // made the epilogue the longest phase of a launch (tools/mx_lab_dbg VB_MX_FLAGS=15 vs 23: 57 us of a 140 us launch spent
 // in an epilogue that stored nothing).
 enum { MX_OUT_F32 = 0, MX_OUT_BF16 = 1, MX_OUT_MX = 2 };
 
-template <int KIND, bool GELU, bool HAS_R>
+template <int KIND, bool GELU, int RES>
 __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
     constexpr bool TRANS = KIND == MX_OUT_MX;
+    constexpr bool HAS_R = RES != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nk = p.K / MX_BK;
     const int b = blockIdx.x, grid = gridDim.x;
@@ -388,16 +391,23 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
             for (int i = 0; i < 2; ++i) {
                 const int rbase = m0 + wm * 64 + 32 * i + 4 * hi;
                 float2 rv[16];
-                if (HAS_R) {
+                if (RES == 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)   // clamped, never predicated (a per-element branch serialises the loads)
                         rv[r] = *reinterpret_cast<const float2*>(p.R + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col);
+                } else if (RES == 2) {
+                    unsigned rw[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rw[r] = *reinterpret_cast<const unsigned*>(p.R16 + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr16 + col);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = float2{__uint_as_float(rw[r] << 16), __uint_as_float(rw[r] & 0xffff0000u)};
                 }
                 float2 v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     v[r] = float2{acc[i][0][r] + bv.x, acc[i][1][r] + bv.y};
-                    if (GELU) v[r] = float2{gelu_erf(v[r].x), gelu_erf(v[r].y)};
+                    if (GELU) v[r] = float2{mx_gelu(v[r].x), mx_gelu(v[r].y)};
                     if (HAS_R) v[r] = float2{v[r].x + rv[r].x, v[r].y + rv[r].y};
                 }
                 if (KIND == MX_OUT_F32) {
@@ -459,14 +469,21 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[q][e] = gelu_erf(v[q][e]);
+                        for (int e = 0; e < 4; ++e) v[q][e] = mx_gelu(v[q][e]);
                 }
-                if (HAS_R) {
+                if (RES == 1) {
                     f32x4 rv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(p.R + mr * p.ldr + nb + 8 * q + 4 * hi);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] += rv[q];
+                } else if (RES == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint2 w = *reinterpret_cast<const uint2*>(p.R16 + mr * p.ldr16 + nb + 8 * q + 4 * hi);
+                        v[q] += f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                                      __uint_as_float(w.y & 0xffff0000u)};
+                    }
                 }
                 // the row's 32-column block = this lane's 16 values + lane ^ 32's 16
                 float amax = fmaxf(fmaxf(amax4(v[0]), amax4(v[1])), fmaxf(amax4(v[2]), amax4(v[3])));
@@ -507,13 +524,13 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
     }
 }
 
-template <int KIND, bool GELU, bool HAS_R>
+template <int KIND, bool GELU, int RES>
 int launch_mx(hipStream_t st, const MxP& p) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<KIND, GELU, HAS_R>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<KIND, GELU, RES>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS);
     if (attr != hipSuccess) return (int)attr;
     const int grid = p.tiles < 256 ? p.tiles : 256;
-    hipLaunchKernelGGL((gemm_mx_kernel<KIND, GELU, HAS_R>), dim3(grid), dim3(MX_THREADS), MX_LDS, st, p);
+    hipLaunchKernelGGL((gemm_mx_kernel<KIND, GELU, RES>), dim3(grid), dim3(MX_THREADS), MX_LDS, st, p);
     VB_LAUNCH_CHECK();
     return 0;
 }
@@ -561,12 +578,15 @@ extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {
     if (a->residual != nullptr && (a->ldr % 4 != 0 || a->ldr < a->N || !vb_aligned16(a->residual))) return VB_E_ALIGN;
     if (a->bias != nullptr && !vb_aligned16(a->bias)) return VB_E_ALIGN;
     if (a->residual != nullptr && a->ldr % 2 != 0) return VB_E_ALIGN;
+    if (a->residual != nullptr && a->residual_bf16 != nullptr) return VB_E_BADARG;
+    if (a->residual_bf16 != nullptr && (a->ldr16 % 4 != 0 || a->ldr16 < a->N || (reinterpret_cast<uintptr_t>(a->residual_bf16) & 7u) != 0))
+        return VB_E_ALIGN;
     if ((long)a->M * a->lda > 0xffffffffL && a->lda * 256 > 0xffffffffL) return VB_E_RANGE;
     MxP p{};
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
     p.A = a->A; p.lda = a->lda; p.sa = a->a_scales; p.sa_rows = a->a_srows;
     p.B = a->W; p.ldb = a->ldw; p.sb = a->w_scales; p.sb_rows = a->w_srows;
-    p.bias = a->bias; p.R = a->residual; p.ldr = a->ldr;
+    p.bias = a->bias; p.R = a->residual; p.ldr = a->ldr; p.R16 = a->residual_bf16; p.ldr16 = a->ldr16;
     p.C = a->C; p.ldc = a->ldc;
     p.Cq = a->Cq; p.ldq = a->ldq; p.cs = a->c_scales; p.cs_rows = a->c_srows;
     p.Cb = a->Cb; p.ldb16 = a->ldb16;
@@ -578,15 +598,20 @@ extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {
     p.flags = flags;
 #endif
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool gelu = a->act == VB_ACT_GELU, res = a->residual != nullptr;
+    const bool gelu = a->act == VB_ACT_GELU;
+    const int res = a->residual != nullptr ? 1 : a->residual_bf16 != nullptr ? 2 : 0;
+    // the combinations the model uses (+ the plain ones); anything else is not built
     if (p.Cq != nullptr) {
-        if (res) return gelu ? launch_mx<MX_OUT_MX, true, true>(st, p) : launch_mx<MX_OUT_MX, false, true>(st, p);
-        return gelu ? launch_mx<MX_OUT_MX, true, false>(st, p) : launch_mx<MX_OUT_MX, false, false>(st, p);
+        if (res == 2) return VB_E_BADARG;
+        if (res == 1) return gelu ? VB_E_BADARG : launch_mx<MX_OUT_MX, false, 1>(st, p);
+        return gelu ? launch_mx<MX_OUT_MX, true, 0>(st, p) : launch_mx<MX_OUT_MX, false, 0>(st, p);
     }
     if (p.Cb != nullptr) {
-        if (res) return gelu ? launch_mx<MX_OUT_BF16, true, true>(st, p) : launch_mx<MX_OUT_BF16, false, true>(st, p);
-        return gelu ? launch_mx<MX_OUT_BF16, true, false>(st, p) : launch_mx<MX_OUT_BF16, false, false>(st, p);
+        if (gelu) return res == 0 ? launch_mx<MX_OUT_BF16, true, 0>(st, p) : VB_E_BADARG;
+        return res == 2 ? launch_mx<MX_OUT_BF16, false, 2>(st, p) : res == 1 ? launch_mx<MX_OUT_BF16, false, 1>(st, p)
+                                                                           : launch_mx<MX_OUT_BF16, false, 0>(st, p);
     }
-    if (res) return gelu ? launch_mx<MX_OUT_F32, true, true>(st, p) : launch_mx<MX_OUT_F32, false, true>(st, p);
-    return gelu ? launch_mx<MX_OUT_F32, true, false>(st, p) : launch_mx<MX_OUT_F32, false, false>(st, p);
+    if (res == 2) return gelu ? VB_E_BADARG : launch_mx<MX_OUT_F32, false, 2>(st, p);
+    if (res == 1) return gelu ? launch_mx<MX_OUT_F32, true, 1>(st, p) : launch_mx<MX_OUT_F32, false, 1>(st, p);
+    return gelu ? launch_mx<MX_OUT_F32, true, 0>(st, p) : launch_mx<MX_OUT_F32, false, 0>(st, p);
 }

@@ -304,6 +304,81 @@ extern "C" int vb_layernorm_fwd_mx(void* stream, int64_t rows, int32_t n_cols, c
     return 0;
 }
 
+namespace {
+// LayerNorm of the MX path's bf16 residual stream: bf16 row in, bf16 row + MX codes out (lane = 4 consecutive columns of
+// every 256-column chunk, as layernorm_kernel)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm16_mx_kernel(long rows, int n_cols, const unsigned short* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, unsigned short* __restrict__ y,
+                                                             unsigned char* __restrict__ q, long ldq, unsigned* __restrict__ mxs,
+                                                             long mxs_rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const unsigned short* xr = x + row * n_cols;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < n_cols) {
+            const uint2 w = *reinterpret_cast<const uint2*>(xr + col);
+            v[i] = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                         __uint_as_float(w.y & 0xffff0000u)};
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)n_cols;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        if (col < n_cols) {
+            v[i] -= mean;
+            var += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)n_cols + eps);
+    const int nkt = n_cols >> 7;
+    auto bf = [](float f) -> unsigned { const unsigned u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4;
+        const bool ok = col < n_cols;
+        if (ok) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
+            v[i] = g * (v[i] * rstd) + b;
+            *reinterpret_cast<uint2*>(y + row * n_cols + col) = uint2{bf(v[i][0]) | (bf(v[i][1]) << 16), bf(v[i][2]) | (bf(v[i][3]) << 16)};
+        }
+        const int kt = 2 * i + (lane >> 5);
+        mx_quant_chunk(v[i], ok, lane, kt, nkt, reinterpret_cast<unsigned*>(q + row * ldq + (ok ? col : 0)),
+                       mxs + (long)(kt < nkt ? kt : 0) * mxs_rows + row);
+    }
+}
+}  // namespace
+
+extern "C" int vb_layernorm_fwd_mx16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* x, const float* gamma,
+                                     const float* beta, float eps, uint16_t* y, uint8_t* q, int64_t ldq, uint32_t* scales,
+                                     int64_t scale_rows) {
+    if (x == nullptr || gamma == nullptr || beta == nullptr || y == nullptr || q == nullptr || scales == nullptr || rows <= 0)
+        return VB_E_BADARG;
+    if (int e = check_cols(n_cols)) return e;
+    if (n_cols % 128 != 0 || scale_rows < rows) return VB_E_RANGE;
+    if ((reinterpret_cast<uintptr_t>(x) & 7u) != 0 || (reinterpret_cast<uintptr_t>(y) & 7u) != 0 || !vb_aligned16(gamma) ||
+        !vb_aligned16(beta) || ldq < n_cols || ldq % 4 != 0 || (reinterpret_cast<uintptr_t>(q) & 3u) != 0 ||
+        (reinterpret_cast<uintptr_t>(scales) & 3u) != 0)
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm16_mx_kernel<NV>), grid, block, 0, st, (long)rows, n_cols, x, gamma,
+                                                      beta, eps, y, q, (long)ldq, scales, (long)scale_rows));
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vb_text_embed_ln_fwd(void* stream, int32_t batch, int32_t n_tok, int32_t hidden, int32_t vocab,
                                     int32_t n_types, int32_t n_tasks,
                                     const int64_t* ids, const int64_t* seg, int32_t pos_offset,

@@ -66,6 +66,7 @@ class LinearMxArgs(ctypes.Structure):
         ("w_scales", ctypes.c_void_p), ("w_srows", ctypes.c_int64),
         ("bias", _c_f32p),
         ("residual", _c_f32p), ("ldr", ctypes.c_int64),
+        ("residual_bf16", ctypes.c_void_p), ("ldr16", ctypes.c_int64),
         ("C", _c_f32p), ("ldc", ctypes.c_int64),
         ("Cb", ctypes.c_void_p), ("ldb16", ctypes.c_int64),
         ("Cq", ctypes.c_void_p), ("ldq", ctypes.c_int64),
@@ -194,6 +195,7 @@ SIGNATURES = {
     "vb_linear_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(LinearMxArgs)]),
     "vb_layernorm_fwd_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P, _I64]),
     "vb_attention_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(AttentionMxArgs)]),
+    "vb_layernorm_fwd_mx16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _F32, _P, _P, _I64, _P, _I64]),
     "vb_act_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "vb_dropout": (ctypes.c_int, [_P, _I64, _P, _P, _P, _F32, _U64]),
     "vb_layernorm_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _P]),

@@ -38,7 +38,7 @@ def ffn(x, w1, b1, act, w2, b2, drop_p=0.0):
           and ops.mx_eligible(w2.shape[1], w2.shape[0], None, biases=[b2]) and x.is_cuda)
     h = ops.linear_fwd(x, [w1], [b1], act, out="mx" if mx else "f32")[0]
     seed = A.next_seed() if drop_p > 0.0 else 0
-    return ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)[0]
+    return ops.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed, out="bf16" if mx and ops.mx_stream_bf16() else "f32")[0]
 
 
 def layer_norm(x, gamma, beta, eps=1e-12):

@@ -4,6 +4,7 @@ Every function here validates its tensors, allocates the outputs with ``torch.em
 and enqueues exactly the kernels of include/vilbert_hip.h on the current stream. No torch arithmetic.
 """
 import ctypes
+import os as _os
 import weakref
 import math
 
@@ -265,6 +266,12 @@ def _mx_weights(weights, biases):
     return m, bias
 
 
+def mx_stream_bf16():
+    """MX inference mode: the residual stream between the layers (GEMM + residual -> LayerNorm -> next residual) is kept in
+    bf16; the fp32 tensors reappear at the encoder's exit (vilbert.py BertModel.forward)."""
+    return N.mx_enabled() and not torch.is_grad_enabled() and _os.environ.get("VB_MX_STREAM", "bf16") == "bf16"
+
+
 def mx_eligible(K, n_out, act=None, drop_p=0.0, want_pre=False, biases=None):
     uniform_bias = biases is None or all(b is None for b in biases) or all(b is not None for b in biases)
     return (N.mx_enabled() and not torch.is_grad_enabled() and K % MX_K_MULTIPLE == 0 and n_out % MX_K_MULTIPLE == 0
@@ -278,6 +285,8 @@ def _mx_of(x, x2, M, K, lead):
     tag = getattr(x, "_vb_mx", None)
     if tag is not None and tag[1] == x._version and tag[0].rows == M and tag[0].K == K and x.is_contiguous():
         return tag[0]
+    if x2.dtype != torch.float32:                        # a bf16 tensor that lost its codes (expand / index of a hidden state)
+        x2 = x2.float()
     return quantize_rows_mx(x2, lead)
 
 
@@ -290,7 +299,10 @@ def _linear_fwd_mx(x, x2, M, K, lead, weights, biases, n_out, act, residual, out
     a.W, a.ldw, a.w_scales, a.w_srows = wm.q.data_ptr(), K, wm.s.data_ptr(), wm.srows
     a.bias = N.dev_f32(bias, "linear bias") if bias is not None else None
     if residual is not None:
-        a.residual, a.ldr = N.dev_f32(residual, "linear residual"), n_out
+        if residual.dtype == torch.bfloat16:            # the MX mode's bf16 residual stream
+            a.residual_bf16, a.ldr16 = residual.data_ptr(), n_out
+        else:
+            a.residual, a.ldr = N.dev_f32(residual, "linear residual"), n_out
     dev = xm.q.device
     if out == "mx":
         y = MxRows(M, n_out, dev, lead)
@@ -507,6 +519,16 @@ def layernorm_fwd(x, gamma, beta, eps, x2=None, want_stats=False):
     rows, cols = _rows(x)
     y = torch.empty_like(x)
     mean = rstd = None
+    if x.dtype == torch.bfloat16:
+        # the MX mode's bf16 residual stream: bf16 pre-LayerNorm sum in, bf16 row + MX codes out
+        if not (N.mx_enabled() and not want_stats and x2 is None and cols % MX_K_MULTIPLE == 0 and x.is_cuda):
+            raise RuntimeError("layernorm: a bfloat16 input is only served in the MX inference mode")
+        m = MxRows(rows, cols, x.device, tuple(x.shape[:-1]))
+        N.check(N.lib().vb_layernorm_fwd_mx16(
+            N.stream_ptr(), rows, cols, x.data_ptr(), N.dev_f32(gamma, "layernorm weight"), N.dev_f32(beta, "layernorm bias"),
+            eps, y.data_ptr(), m.q.data_ptr(), cols, m.s.data_ptr(), m.srows), "vb_layernorm_fwd_mx16")
+        y._vb_mx = (m, y._version)
+        return y, None, None
     if N.mx_enabled() and not want_stats and not torch.is_grad_enabled() and cols % MX_K_MULTIPLE == 0 and x.is_cuda:
         # inference in the MX mode: the LayerNorm kernel also emits its output rows as MX codes + scale words
         if x2 is not None:

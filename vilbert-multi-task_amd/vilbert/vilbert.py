@@ -276,7 +276,9 @@ class BertSelfAttention(nn.Module):
 def _dense_dropout_add_norm(dense, dropout, norm, hidden_states, input_tensor):
     """LayerNorm(dropout(dense(h)) + input): bias, dropout mask and residual add are all the GEMM epilogue
     (training and eval), followed by one LayerNorm pass."""
-    return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor, drop_p=_drop_p(dropout)))
+    # (MX inference mode: the sum leaves the GEMM as bf16 and the LayerNorm keeps the residual stream in bf16)
+    return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor, drop_p=_drop_p(dropout),
+                         out="bf16" if ops.mx_stream_bf16() else "f32"))
 
 
 def _ffn(intermediate, output, x):
@@ -891,6 +893,9 @@ class BertModel(BertPreTrainedModel):
             output_all_encoded_layers=output_all_encoded_layers,
             output_all_attention_masks=output_all_attention_masks)
 
+        # MX inference mode: the encoder keeps its residual stream in bf16; the callers (poolers, heads, users) get fp32
+        encoded_layers_t = [t.float() if t.dtype == torch.bfloat16 else t for t in encoded_layers_t]
+        encoded_layers_v = [t.float() if t.dtype == torch.bfloat16 else t for t in encoded_layers_v]
         sequence_output_t, sequence_output_v = encoded_layers_t[-1], encoded_layers_v[-1]
         pooled_output_t = self.t_pooler(sequence_output_t)
         pooled_output_v = self.v_pooler(sequence_output_v)
