@@ -734,12 +734,43 @@ def main():
                                                "v_mfma_scale_f32_32x32x64_f8f6f4), codes emitted by LayerNorm / the GELU "
                                                "epilogue (no quantiser pass, no fp32 FFN activation); attention, LayerNorm "
                                                "statistics and the residual stream stay fp32; fp8 dense MFMA peak 5000 TF"}
+            # its own roofline object: every MX / fp8 GEMM launch of two more forwards bracketed with HIP events, single stream
+            # (as the headline's); bound: the scaled-MFMA peak. Counter-side bytes of the dominant launch: tools/pmc_mx.sh
+            two_mx = _vb.set_two_streams(False)
+            fstep()
+            torch.cuda.synchronize()
+            ops.profile_linear(True)
+            fstep()
+            fstep()
+            torch.cuda.synchronize()
+            mx_ms, mx_fl, mx_n = ops.profile_linear(False)
+            _vb.set_two_streams(two_mx)
+            mx_roof = {"bound": "mfma", "kernel": "gemm_mx_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, persistent 256x128 tiles, "
+                       "8 MFMA + 2 LDS-DMA loader waves per CU) + gemm_fp8_kernel on the ragged-N heads",
+                       "achieved": round(mx_fl / (mx_ms * 1e-3) / 1e12, 1) if mx_ms > 0 else 0.0, "peak": 5000.0,
+                       "unit": "TFLOP/s", "frac": round(mx_fl / (mx_ms * 1e-3) / 1e12 / 5000.0, 4) if mx_ms > 0 else 0.0,
+                       "launches_per_forward": mx_n // 2, "avg_launch_us": round(1e3 * mx_ms / max(mx_n, 1), 2),
+                       "what": "all linear launches of 2 forwards, algorithmic 2MNK / sum of HIP-event durations (single stream)",
+                       "traffic": None}
+            tp = os.path.join(ROOT, "profiles", "r04_mx_gemm_traffic.json")
+            if os.path.isfile(tp):
+                t0 = json.load(open(tp))["launches"][0]
+                mx_roof["traffic"] = t0["hbm_bytes_corrected"]
+                mx_roof["traffic_note"] = "rocprofv3 PMC, %s M=%d N=%d K=%d: %.0f MB per launch vs %.0f MB algorithmic (profiles/%s)" % (
+                    t0["kernel"], t0["M"], t0["N"], t0["K"], t0["hbm_bytes_corrected"] / 1e6, t0["algorithmic_bytes"] / 1e6,
+                    os.path.basename(tp))
+            extra["fwd_mxfp8_b512"]["roofline"] = mx_roof
+            emx, _, _ = forward_workload(128)
+            emx_dt = timed(emx, 2, n128)
             gmx, _, _ = forward_workload(128, graph=True)
             gmx_dt = timed(gmx, 2, n128)
-            extra["fwd_mxfp8_b128"] = {"value": round(128 * n128 / gmx_dt, 2), "unit": "samples/s",
-                                       "ms_per_step": round(1e3 * gmx_dt / n128, 3), "steps": n128,
-                                       "note": "per-GPU share of BASELINE configs[4] (128 per GPU) in the MX mode, one HIP graph"}
-            del gmx
+            extra["fwd_mxfp8_b128"] = {"value": round(128 * n128 / min(emx_dt, gmx_dt), 2), "unit": "samples/s",
+                                       "eager": round(128 * n128 / emx_dt, 2), "graphed": round(128 * n128 / gmx_dt, 2),
+                                       "ms_per_step": round(1e3 * min(emx_dt, gmx_dt) / n128, 3), "steps": n128,
+                                       "note": "per-GPU share of BASELINE configs[4] (128 per GPU) in the MX mode: eager launches vs "
+                                               "one HIP graph (stand-alone A/B of the same two: tools/mx_b128_ab.py, "
+                                               "profiles/r04_mx_b128_ab.txt - 22.8 k eager, 34.0 k graphed)"}
+            del emx, gmx
         finally:
             _native.set_gemm_mode("f32")
         del fstep, fmodel

@@ -683,8 +683,9 @@ int plan_v4(const GemmP& p, bool b_kc, double v2_cost) {
     // 32 x 32-tile K steps (53.4 ns on a saturated CU) and tracks the measured time (x 0.93) while a CU holds at most two
     // 4-wave blocks - beyond that (large M, where the menu has nothing to offer anyway) it is not calibrated: 4-wave.
     if (best_fills || best_mixed) return best_cfg;
-    // The small-M menu wins every isolated A/B (+8 ... +19 % at M = 2304 / 2368) and LOSES inside the batch-64 training step
-    // (1,866 vs 1,954 samples/s, profiles/r04_bench_b64_menu_ab.txt): there the text / image / weight-gradient streams keep
+    // The small-M menu wins every isolated A/B (+8 ... +19 % at M = 2304 / 2368) and is a WASH inside the batch-64 training
+    // step (profiles/r04_bench_b64_menu_ab.txt: 1,986 -> 2,022 samples/s eager, 1,716 -> 1,773 single-stream, 1,887 -> 1,932 as
+    // one HIP graph on one box; 1,954 -> 1,866 on an earlier one): there the text / image / weight-gradient streams keep
     // several kernels in flight, the 4-wave blocks of different kernels co-reside on a CU and cover each other's bubbles,
     // while a persistent block owns its CU - so it is opt-in (VB_GEMM_V4_SMALLM=1: single-stream inference, laboratory).
     static const bool small_m = [] { const char* e = getenv("VB_GEMM_V4_SMALLM"); return e != nullptr && atoi(e) != 0; }();
