@@ -679,11 +679,12 @@ int plan_v4(const GemmP& p, bool b_kc, double v2_cost) {
     if (mode == 2 || force_cfg != 0) return best_cfg;
     // mode 1. Measured (in-process A/B on every shape of the model, profiles/r03_gemm_lab_v4_ab_*.txt,
     // r04_gemm_lab_v4_menu_*.txt): the 288-row shapes that fill the chip and the mixed launch beat the 4-wave blocks on
-    // every forward / dgrad shape (+3 ... +13 %). For the small-M menu the two models are compared; plan_v2's cost is in
+    // every forward / dgrad shape but one (+4 ... +14 %; 9472 x 1024 x 3 x 1024 forward: -1 %). For the small-M menu the two models are compared; plan_v2's cost is in
     // 32 x 32-tile K steps (53.4 ns on a saturated CU) and tracks the measured time (x 0.93) while a CU holds at most two
     // 4-wave blocks - beyond that (large M, where the menu has nothing to offer anyway) it is not calibrated: 4-wave.
     if (best_fills || best_mixed) return best_cfg;
-    // The small-M menu wins every isolated A/B (+8 ... +19 % at M = 2304 / 2368) and is a WASH inside the batch-64 training
+    // The small-M menu wins most isolated A/Bs (profiles/r04_gemm_lab_v4_menu_M2304.txt / _M2368.txt, planner's choice against the
+    // 4-wave blocks: +8 ... +20 % on 15 of 20 forward / dgrad launches, -1 ... -13 % on 5) and is a WASH inside the batch-64 training
     // step (profiles/r04_bench_b64_menu_ab.txt: 1,986 -> 2,022 samples/s eager, 1,716 -> 1,773 single-stream, 1,887 -> 1,932 as
     // one HIP graph on one box; 1,954 -> 1,866 on an earlier one): there the text / image / weight-gradient streams keep
     // several kernels in flight, the 4-wave blocks of different kernels co-reside on a CU and cover each other's bubbles,

@@ -718,10 +718,56 @@ def _attn_args(q, k, v, mask_add, heads, drop_p, seed):
     return a, keep, (B, Sq, Sk, H)
 
 
+MAX_KEYS = 320          # include/vilbert_hip.h VB_MAX_KEYS: longest key sequence ONE attention launch handles
+
+
+def merge_attention_chunks(outs, lses, heads):
+    """Contexts of the SAME queries over disjoint key chunks -> the context over the union of the keys.
+    outs[c]: [B, Sq, H], softmax-normalised over chunk c's keys only; lses[c]: [B, heads, Sq] = log sum_k exp(score) of
+    that chunk. softmax over the union = sum_c w_c softmax_c with w_c = exp(lse_c - logsumexp_c lse_c) - exact, the
+    identity flash attention tiles by. Returns (ctx [B, Sq, H], lse over all keys [B, heads, Sq])."""
+    lse = torch.stack(lses)                                      # [C, B, heads, Sq]
+    total = torch.logsumexp(lse, dim=0)
+    w = torch.exp(lse - total)
+    B, Sq, H = outs[0].shape
+    d = H // heads
+    out = None
+    for c, o in enumerate(outs):
+        term = o.reshape(B, Sq, heads, d) * w[c].permute(0, 2, 1).unsqueeze(-1)
+        out = term if out is None else out + term
+    return out.reshape(B, Sq, H), total
+
+
+def _attention_fwd_long(q, k, v, mask_add, heads, want_lse):
+    """More than MAX_KEYS keys (inference: stacked retrieval options, in_batch_pairs): one launch per chunk of <= MAX_KEYS
+    keys, merged with merge_attention_chunks (a few small torch ops - this is the rare path; the shapes of every task in
+    vilbert_tasks.yml fit one launch)."""
+    Bk, Sk, _ = k.shape
+    if mask_add is not None:
+        mask_add = _contig(mask_add).reshape(Bk, Sk)
+    n_chunks = (Sk + MAX_KEYS - 1) // MAX_KEYS
+    step = (Sk + n_chunks - 1) // n_chunks
+    outs, lses = [], []
+    for c0 in range(0, Sk, step):
+        c1 = min(Sk, c0 + step)
+        m = mask_add[:, c0:c1].contiguous() if mask_add is not None else None
+        o, _, l = attention_fwd(q, k[:, c0:c1].contiguous(), v[:, c0:c1].contiguous(), m, heads, False, True)
+        outs.append(o)
+        lses.append(l)
+    out, total = merge_attention_chunks(outs, lses, heads)
+    return out, None, (total if want_lse else None)
+
+
 def attention_fwd(q, k, v, mask_add, heads, want_probs=False, want_lse=False, drop_p=0.0, seed=0):
     """q: [Bq, Sq, H*] view, k/v: [Bk, Sk, H*] views (last dim contiguous, uniform row stride, e.g. column
     slices of a fused [q|k|v] projection); mask_add: [Bk, 1, 1, Sk] or [Bk, Sk] fp32 additive, or None.
-    Bq / Bk may be 1 against a larger batch (broadcast). Returns (ctx [B, Sq, H], probs|None, lse|None)."""
+    Bq / Bk may be 1 against a larger batch (broadcast). Returns (ctx [B, Sq, H], probs|None, lse|None).
+    More than MAX_KEYS keys: served chunk by chunk when neither probabilities nor dropout are wanted (inference)."""
+    if k.shape[1] > MAX_KEYS:
+        if want_probs or drop_p > 0.0:
+            raise RuntimeError("attention: %d keys - more than %d keys are served without dropout / probabilities only"
+                               % (k.shape[1], MAX_KEYS))
+        return _attention_fwd_long(q, k, v, mask_add, heads, want_lse)
     a, keep, (B, Sq, Sk, H) = _attn_args(q, k, v, mask_add, heads, drop_p, seed)
     out = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
     probs = torch.empty(B, heads, Sq, Sk, dtype=torch.float32, device=q.device) if want_probs else None
