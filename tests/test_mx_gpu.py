@@ -372,3 +372,22 @@ def test_bf16_stream_layernorm_and_residual(mx_mode, rows, cols):
         s32, _ = ops.linear_fwd(xin, [w], [bias], None, y.float())
     assert s16.dtype == torch.bfloat16 and s32.dtype == torch.float32
     assert (s16.double() - s32.double()).abs().le(s32.double().abs() / 256 + 1e-6).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 1601, 1024), (77, 3129, 2048), (40, 30522, 768)])
+def test_ragged_heads_run_on_a_zero_padded_weight_copy(mx_mode, M, N, K):
+    """Heads whose width is not a multiple of the GEMM's 128-column tile (1601 region classes, 3129 answers, the 30522-wide MLM
+    decoder): MX GEMM on a weight copy padded with all-zero rows, result = a column slice of the padded output."""
+    from vilbert import ops
+    g_ = torch.Generator().manual_seed(N)
+    x = torch.randn(M, K, generator=g_)
+    w = torch.randn(N, K, generator=g_) * 0.05
+    b = torch.randn(N, generator=g_)
+    with torch.no_grad():
+        y, _ = ops.linear_fwd(x.to(DEV), [w.to(DEV)], [b.to(DEV)])
+    assert y.shape == (M, N) and y.stride(0) % 128 == 0 and y.stride(0) >= N
+    want = F.linear_mx(x.numpy(), w.numpy(), b.numpy())
+    mag = np.abs(F.mx_dequantize(*F.mx_quantize(x.numpy()))) @ np.abs(F.mx_dequantize(*F.mx_quantize(w.numpy()))).T + 1.0
+    assert (np.abs(y.cpu().numpy().astype(np.float64) - want) <= 1e-4 * mag).all()
+    exact = x.double() @ w.double().t() + b.double()
+    assert ((y.cpu().double() - exact).norm() / exact.norm()).item() <= 0.06

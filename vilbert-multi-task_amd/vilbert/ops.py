@@ -230,12 +230,15 @@ def mx_cache_clear():
     _MX_WEIGHTS.clear()
 
 
-def _mx_weights(weights, biases):
-    """MX copy of the (stacked) weight, cached like `_fp8_weights` (same invalidation rules)."""
+def _mx_weights(weights, biases, n_pad=None):
+    """MX copy of the (stacked) weight, cached like `_fp8_weights` (same invalidation rules). n_pad > rows: the copy has
+    n_pad rows, the extra ones all-zero codes with scale byte 0 (a head whose width is not a multiple of the GEMM's 128-column
+    tile: its extra output columns are computed as 0 + 0 and never shown)."""
     key = tuple(w.data_ptr() for w in weights)
     vers = tuple(w._version for w in weights) + tuple(-1 if b is None else b._version for b in (biases or []))
     seg_n, K = weights[0].shape
-    n = seg_n * len(weights)
+    n_real = seg_n * len(weights)
+    n = n_real if n_pad is None else n_pad
     hit = _MX_WEIGHTS.get(key)
     if hit is not None and hit[2].q.shape != (n, K):
         hit = None
@@ -249,12 +252,19 @@ def _mx_weights(weights, biases):
         for k in dead:
             del _MX_WEIGHTS[k]
         m, bias = MxRows(n, K, dev, (n,)), None
+        if n != n_real:
+            m.q.zero_()
+            m.s.zero_()
     with torch.no_grad():
         cat = weights[0].detach() if len(weights) == 1 else torch.cat([w.detach() for w in weights])
-        quantize_rows_mx(cat, out=m)
+        quantize_rows_mx(cat, out=m)                # writes rows [0, n_real) of the codes and of every scale plane
         if biases is not None and all(b is not None for b in biases):
             bcat = biases[0].detach() if len(biases) == 1 else torch.cat([b.detach() for b in biases])
-            if bias is None or len(biases) == 1:
+            if n != n_real:
+                if bias is None:
+                    bias = torch.zeros(n, dtype=torch.float32, device=dev)
+                bias[:n_real].copy_(bcat)
+            elif bias is None or len(biases) == 1:
                 bias = bcat
             else:
                 bias.copy_(bcat)
@@ -278,6 +288,16 @@ def mx_eligible(K, n_out, act=None, drop_p=0.0, want_pre=False, biases=None):
             and act in (None, "none", "gelu") and drop_p == 0.0 and not want_pre and uniform_bias)
 
 
+MX_PAD_MIN_N = 256       # heads at least this wide whose width is not a multiple of 128 run on a zero-padded weight copy
+
+
+def _mx_pad_eligible(K, n_out, act, drop_p, want_pre, biases, residual, out):
+    """A wide head with a ragged width (the 30522-wide MLM decoder, 1601 region classes, 3129 / 1533 answers): served by the
+    MX GEMM on a weight copy padded to the next multiple of 128 rows, result = a column slice of the padded output."""
+    return (n_out % MX_K_MULTIPLE != 0 and n_out >= MX_PAD_MIN_N and residual is None and out == "f32"
+            and mx_eligible(K, (n_out + MX_K_MULTIPLE - 1) // MX_K_MULTIPLE * MX_K_MULTIPLE, act, drop_p, want_pre, biases))
+
+
 def _mx_of(x, x2, M, K, lead):
     """MX form of the input: the object itself, the codes its producer attached (LayerNorm), or a quantiser pass."""
     if isinstance(x, MxRows):
@@ -292,7 +312,9 @@ def _mx_of(x, x2, M, K, lead):
 
 def _linear_fwd_mx(x, x2, M, K, lead, weights, biases, n_out, act, residual, out):
     """out: "f32" -> fp32 tensor, "mx" -> MxRows of the result (no fp32 copy), "bf16" -> bfloat16 tensor."""
-    wm, bias = _mx_weights(weights, biases)
+    n_real = n_out
+    n_out = (n_out + MX_K_MULTIPLE - 1) // MX_K_MULTIPLE * MX_K_MULTIPLE      # (a padded head: see _mx_pad_eligible)
+    wm, bias = _mx_weights(weights, biases, n_out if n_out != n_real else None)
     xm = _mx_of(x, x2, M, K, lead)
     a = N.LinearMxArgs()
     a.A, a.lda, a.a_scales, a.a_srows = xm.q.data_ptr(), K, xm.s.data_ptr(), xm.srows
@@ -316,8 +338,8 @@ def _linear_fwd_mx(x, x2, M, K, lead, weights, biases, n_out, act, residual, out
     a.M, a.N, a.K = M, n_out, K
     a.act = N.ACT_CODES[act]
     _timed(lambda: N.check(N.lib().vb_linear_fwd_mx(N.stream_ptr(), ctypes.byref(a)), "vb_linear_fwd_mx"),
-           2.0 * M * n_out * K, ("fwd_mx", M, n_out, K, 1))
-    return y
+           2.0 * M * n_real * K, ("fwd_mx", M, n_real, K, 1))
+    return y if n_out == n_real else y[..., :n_real]
 
 
 def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, drop_p=0.0, seed=0,
@@ -343,9 +365,11 @@ def linear_fwd(x, weights, biases, act=None, residual=None, want_preact=False, d
     if x.shape[-1] != K:
         raise RuntimeError("linear: input has %d features, weight expects %d" % (x.shape[-1], K))
     n_out = nseg * seg_n
-    if isinstance(x, MxRows) or (N.mx_enabled() and mx_eligible(K, n_out, act, drop_p, want_preact or want_act_grad, biases)
-                                 and x.is_cuda):
-        if not mx_eligible(K, n_out, act, drop_p, want_preact or want_act_grad, biases):
+    want_pre_any = want_preact or want_act_grad
+    mx_ok = N.mx_enabled() and (mx_eligible(K, n_out, act, drop_p, want_pre_any, biases)
+                                or _mx_pad_eligible(K, n_out, act, drop_p, want_pre_any, biases, residual, out))
+    if isinstance(x, MxRows) or (mx_ok and x.is_cuda):
+        if not mx_ok:
             raise RuntimeError("linear: an MX input needs an MX-eligible linear (K, N multiples of 128, no dropout)")
         for w in weights:
             if w.shape != (seg_n, K) or not w.is_contiguous():
