@@ -306,7 +306,20 @@ extern "C" int vb_layernorm_fwd_mx(void* stream, int64_t rows, int32_t n_cols, c
 
 namespace {
 // LayerNorm of the MX path's bf16 residual stream: bf16 row in, bf16 row + MX codes out (lane = 4 consecutive columns of
-// every 256-column chunk, as layernorm_kernel)
+// every 256-column chunk, as layernorm_kernel). A wave owns TWO rows and runs their dependent chains (load -> sum -> wave
+// reduction -> squared deviations -> wave reduction -> codes) side by side: with one row per wave the launch was bound by
+// that chain's latency times the number of block rounds (29.5 us for 70 MB at 18,432 x 768), not by HBM.
+constexpr int LN16_RPW = 2;
+
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ta = __shfl_xor(a, off, 64), tb = __shfl_xor(b, off, 64);
+        a += ta;
+        b += tb;
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm16_mx_kernel(long rows, int n_cols, const unsigned short* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -314,48 +327,68 @@ __global__ __launch_bounds__(256) void layernorm16_mx_kernel(long rows, int n_co
                                                              unsigned char* __restrict__ q, long ldq, unsigned* __restrict__ mxs,
                                                              long mxs_rows) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const unsigned short* xr = x + row * n_cols;
-    f32x4 v[NV];
-    float s = 0.f;
+    const long row0 = ((long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * LN16_RPW;
+    if (row0 >= rows) return;
+    const bool two = row0 + 1 < rows;                   // (wave-uniform) the second row exists
+    const long rrow[LN16_RPW] = {row0, two ? row0 + 1 : row0};
+    f32x4 v[LN16_RPW][NV];
+    float s[LN16_RPW] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int col = (i * 64 + lane) * 4;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (col < n_cols) {
-            const uint2 w = *reinterpret_cast<const uint2*>(xr + col);
-            v[i] = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
-                         __uint_as_float(w.y & 0xffff0000u)};
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    for (int r = 0; r < LN16_RPW; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col < n_cols) {
+                const uint2 w = *reinterpret_cast<const uint2*>(x + rrow[r] * n_cols + col);
+                v[r][i] = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                                __uint_as_float(w.y & 0xffff0000u)};
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < LN16_RPW; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);   // (columns past n_cols hold 0)
+    wave_sum2(s[0], s[1]);
+    float var[LN16_RPW] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < LN16_RPW; ++r) {
+        const float mean = s[r] / (float)n_cols;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            if (col < n_cols) {
+                v[r][i] -= mean;
+                var[r] += (v[r][i][0] * v[r][i][0] + v[r][i][1] * v[r][i][1]) + (v[r][i][2] * v[r][i][2] + v[r][i][3] * v[r][i][3]);
+            }
         }
     }
-    const float mean = wave_sum(s) / (float)n_cols;
-    float var = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int col = (i * 64 + lane) * 4;
-        if (col < n_cols) {
-            v[i] -= mean;
-            var += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)n_cols + eps);
+    wave_sum2(var[0], var[1]);
     const int nkt = n_cols >> 7;
     auto bf = [](float f) -> unsigned { const unsigned u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * 4;
         const bool ok = col < n_cols;
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ok) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
-            v[i] = g * (v[i] * rstd) + b;
-            *reinterpret_cast<uint2*>(y + row * n_cols + col) = uint2{bf(v[i][0]) | (bf(v[i][1]) << 16), bf(v[i][2]) | (bf(v[i][3]) << 16)};
+            g = *reinterpret_cast<const f32x4*>(gamma + col);
+            b = *reinterpret_cast<const f32x4*>(beta + col);
         }
         const int kt = 2 * i + (lane >> 5);
-        mx_quant_chunk(v[i], ok, lane, kt, nkt, reinterpret_cast<unsigned*>(q + row * ldq + (ok ? col : 0)),
-                       mxs + (long)(kt < nkt ? kt : 0) * mxs_rows + row);
+#pragma unroll
+        for (int r = 0; r < LN16_RPW; ++r) {
+            const float rstd = 1.0f / sqrtf(var[r] / (float)n_cols + eps);
+            const bool live = ok && (r == 0 || two);
+            if (ok) v[r][i] = g * (v[r][i] * rstd) + b;
+            if (live)
+                *reinterpret_cast<uint2*>(y + rrow[r] * n_cols + col) =
+                    uint2{bf(v[r][i][0]) | (bf(v[r][i][1]) << 16), bf(v[r][i][2]) | (bf(v[r][i][3]) << 16)};
+            // (the cross-lane steps inside run for every lane; the stores of the row that does not exist are masked)
+            mx_quant_chunk(v[r][i], live, lane, (r == 0 || two) ? kt : nkt, nkt,
+                           reinterpret_cast<unsigned*>(q + rrow[r] * ldq + (ok ? col : 0)),
+                           mxs + (long)(kt < nkt ? kt : 0) * mxs_rows + rrow[r]);
+        }
     }
 }
 }  // namespace
@@ -372,7 +405,8 @@ extern "C" int vb_layernorm_fwd_mx16(void* stream, int64_t rows, int32_t n_cols,
         (reinterpret_cast<uintptr_t>(scales) & 3u) != 0)
         return VB_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    constexpr int per_block = ROWS_PER_BLOCK * LN16_RPW;
+    dim3 grid((unsigned)((rows + per_block - 1) / per_block)), block(256);
     VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm16_mx_kernel<NV>), grid, block, 0, st, (long)rows, n_cols, x, gamma,
                                                       beta, eps, y, q, (long)ldq, scales, (long)scale_rows));
     VB_LAUNCH_CHECK();
