@@ -37,6 +37,7 @@ struct AttnMxP {
     float scale;
     unsigned char* Oq; long ldo;         // codes [batch * n_q][heads * D]
     unsigned* os; long os_rows;          // scale words [heads * D / 128][os_rows]
+    int v_rows;                          // V rows each wave stages in LDS (= n_k: tile rows past it are read as row n_k - 1)
 };
 
 __device__ __forceinline__ unsigned short bf16_bits(float v) {
@@ -47,7 +48,9 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
 constexpr int AMX_ROWS = 48;
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_mx_kernel(const AttnMxP p) {
+// four waves per SIMD (<= 128 registers): 16 waves x 256 CUs = the 4096 (sample, head) pairs of the image stream at batch 512 in one
+// round (head_dim 64 compiles to 108 registers without a bound; five or six waves per SIMD would spill)
+__global__ __launch_bounds__(256, 4) void attn_mx_kernel(const AttnMxP p) {
     constexpr int LDV = D + 8;                       // LDS row stride in bf16 elements (+ 16 bytes)
     constexpr int DT = D / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_v[];
@@ -56,19 +59,22 @@ __global__ __launch_bounds__(256) void attn_mx_kernel(const AttnMxP p) {
     if (item >= (long)p.batch * p.heads) return;
     const int b = (int)(item / p.heads), h = (int)(item % p.heads);
     const int c = lane & 15, g = lane >> 4;
-    unsigned short* __restrict__ vs = smem_v + wave * (AMX_ROWS * LDV);
+    unsigned short* __restrict__ vs = smem_v + wave * (p.v_rows * LDV);
     const unsigned short* __restrict__ Qg = p.Q + (long)b * p.q_bstride * p.ldq + h * D;
     const unsigned short* __restrict__ Kg = p.K + (long)b * p.kv_bstride * p.ldk + h * D;
     const unsigned short* __restrict__ Vg = p.V + (long)b * p.kv_bstride * p.ldv + h * D;
     const int n_qt = p.n_qt, n_kt = p.n_kt;
 
-    // ---- stage V (this wave's region; rows past n_k repeat the last row: they only ever meet a probability of exactly 0)
+    // ---- stage V: exactly n_k rows (this wave's region). Tile rows past n_k are READ as row n_k - 1 below: they only ever
+    // meet a probability of exactly 0. Staging n_k instead of 48 rows keeps the block at 4 x n_k x (D + 8) x 2 bytes - four
+    // blocks per CU at head_dim 128 and n_k <= 37 (16 waves x 256 CUs = the 4096 (sample, head) pairs of the image stream at
+    // batch 512 in ONE round instead of 1.33).
     {
         constexpr int CH = D / 8;                    // 16-byte chunks per row
-        const int total = n_kt * 16 * CH;
+        const int total = p.n_k * CH;
         for (int idx = lane; idx < total; idx += 64) {
             const int row = idx / CH, ch = idx % CH;
-            const v4i val = *reinterpret_cast<const v4i*>(Vg + (long)min(row, p.n_k - 1) * p.ldv + ch * 8);
+            const v4i val = *reinterpret_cast<const v4i*>(Vg + (long)row * p.ldv + ch * 8);
             *reinterpret_cast<v4i*>(vs + row * LDV + ch * 8) = val;
         }
     }
@@ -144,55 +150,70 @@ __global__ __launch_bounds__(256) void attn_mx_kernel(const AttnMxP p) {
         }
     }
 
-    // ---- context: o[dt][qt][r] = O[q = 16 qt + c][d = 16 dt + 4 g + r]
-    f32x4 o[DT][3];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int qt = 0; qt < 3; ++qt) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- context, 64 head dims (4 d tiles = two 32-column MX blocks) at a time: o[dl][qt][r] = O[q = 16 qt + c][d = 64 half +
+    // 16 dl + 4 g + r]. Half the accumulators of a whole head at head_dim 128 (48 instead of 96 registers): the kernel fits
+    // four waves per SIMD, the MX blocks of a half are complete in it.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's V rows are in LDS (wave-private region)
+    unsigned word[3] = {0u, 0u, 0u};     // per query tile: the scale bytes of the head's blocks
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-        if (kt < n_kt) {
-            const unsigned short* __restrict__ vb = vs + (16 * kt + 4 * g) * LDV + c;
+    for (int half = 0; half < D / 64; ++half) {
+        f32x4 o[4][3];
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                s16x4 va;   // A operand: row d = 16 dt + c, slot j <-> key 16 kt + 4 g + j
+        for (int dl = 0; dl < 4; ++dl)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) va[j] = (short)vb[j * LDV + 16 * dt];
+            for (int qt = 0; qt < 3; ++qt) o[dl][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int qt = 0; qt < 3; ++qt)
-                    if (qt < n_qt) o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb[kt][qt], o[dt][qt], 0, 0, 0);
+        for (int kt = 0; kt < 3; ++kt) {
+            if (kt < n_kt) {
+                int voff[4];   // LDS offsets of the lane group's four key rows (clamped to the last staged row)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) voff[j] = min(16 * kt + 4 * g + j, p.n_k - 1) * LDV + c + 64 * half;
+#pragma unroll
+                for (int dl = 0; dl < 4; ++dl) {
+                    s16x4 va;   // A operand: row d = 64 half + 16 dl + c, slot j <-> key 16 kt + 4 g + j
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) va[j] = (short)vs[voff[j] + 16 * dl];
+#pragma unroll
+                    for (int qt = 0; qt < 3; ++qt)
+                        if (qt < n_qt) o[dl][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(va, pb[kt][qt], o[dl][qt], 0, 0, 0);
+                }
+            }
+        }
+        // MX codes of this half's two blocks
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt) {
+            if (qt < n_qt) {
+                const int q = 16 * qt + c;
+                const bool live = q < p.n_q;
+                const long row = (long)b * p.n_q + (live ? q : 0);
+#pragma unroll
+                for (int bl = 0; bl < 2; ++bl) {
+                    const int blk = 2 * half + bl;
+                    float amax = fmaxf(amax4(o[2 * bl][qt]), amax4(o[2 * bl + 1][qt]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    const unsigned byte = mx_scale_byte(amax);
+                    const float inv = mx_inv_scale(byte);
+                    word[qt] |= byte << (8 * blk);
+                    if (live) {
+                        unsigned char* __restrict__ dst = p.Oq + row * p.ldo + h * D + 32 * blk + 4 * g;
+                        *reinterpret_cast<unsigned*>(dst) = mx_pack4(o[2 * bl][qt], inv);
+                        *reinterpret_cast<unsigned*>(dst + 16) = mx_pack4(o[2 * bl + 1][qt], inv);
+                    }
+                }
             }
         }
     }
-
-    // ---- MX codes + scale words of the context rows
-    const long kv_unused = 0; (void)kv_unused;
+    // scale words of the context rows
 #pragma unroll
     for (int qt = 0; qt < 3; ++qt) {
-        if (qt >= n_qt) break;
-        const int q = 16 * qt + c;
-        const bool live = q < p.n_q;
-        const long row = (long)b * p.n_q + (live ? q : 0);
-        unsigned word = 0;
-#pragma unroll
-        for (int blk = 0; blk < D / 32; ++blk) {
-            float amax = fmaxf(amax4(o[2 * blk][qt]), amax4(o[2 * blk + 1][qt]));
-            amax = fmaxf(amax, __shfl_xor(amax, 16));
-            amax = fmaxf(amax, __shfl_xor(amax, 32));
-            const unsigned byte = mx_scale_byte(amax);
-            const float inv = mx_inv_scale(byte);
-            word |= byte << (8 * blk);
-            if (live) {
-                unsigned char* __restrict__ dst = p.Oq + row * p.ldo + h * D + 32 * blk + 4 * g;
-                *reinterpret_cast<unsigned*>(dst) = mx_pack4(o[2 * blk][qt], inv);
-                *reinterpret_cast<unsigned*>(dst + 16) = mx_pack4(o[2 * blk + 1][qt], inv);
+        if (qt < n_qt) {
+            const int q = 16 * qt + c;
+            if (q < p.n_q && g == 0) {
+                const long row = (long)b * p.n_q + q;
+                if (D == 128) p.os[(long)h * p.os_rows + row] = word[qt];
+                else reinterpret_cast<unsigned short*>(p.os + (long)(h >> 1) * p.os_rows + row)[h & 1] = (unsigned short)word[qt];
             }
-        }
-        if (live && g == 0) {
-            if (D == 128) p.os[(long)h * p.os_rows + row] = word;
-            else reinterpret_cast<unsigned short*>(p.os + (long)(h >> 1) * p.os_rows + row)[h & 1] = (unsigned short)word;
         }
     }
 }
@@ -222,11 +243,12 @@ extern "C" int vb_attention_fwd_mx(void* stream, const vb_attention_mx_args* a) 
     const long items = (long)a->batch * a->heads;
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    p.v_rows = a->n_k;
     if (a->head_dim == 128) {
-        constexpr int lds = 4 * AMX_ROWS * (128 + 8) * 2;
+        const int lds = 4 * p.v_rows * (128 + 8) * 2;
         hipLaunchKernelGGL(attn_mx_kernel<128>, grid, block, lds, st, p);
     } else {
-        constexpr int lds = 4 * AMX_ROWS * (64 + 8) * 2;
+        const int lds = 4 * p.v_rows * (64 + 8) * 2;
         hipLaunchKernelGGL(attn_mx_kernel<64>, grid, block, lds, st, p);
     }
     VB_LAUNCH_CHECK();
