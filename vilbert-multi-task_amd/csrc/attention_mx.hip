@@ -45,14 +45,13 @@ __device__ __forceinline__ unsigned short bf16_bits(float v) {
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-constexpr int AMX_ROWS = 48;
+constexpr int AMX_ROWS = 48;           // longest query / key sequence (three 16-row tiles)
 
 template <int D>
 // four waves per SIMD (<= 128 registers): 16 waves x 256 CUs = the 4096 (sample, head) pairs of the image stream at batch 512 in one
 // round (head_dim 64 compiles to 108 registers without a bound; five or six waves per SIMD would spill)
 __global__ __launch_bounds__(256, 4) void attn_mx_kernel(const AttnMxP p) {
     constexpr int LDV = D + 8;                       // LDS row stride in bf16 elements (+ 16 bytes)
-    constexpr int DT = D / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_v[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long item = (long)blockIdx.x * 4 + wave;
