@@ -115,7 +115,32 @@ print(vilbert.utils.PreTrainedModel.__module__, vilbert.utils.tbLogger.__module_
     assert p.returncode == 0, p.stderr[-2000:]
     ours, utils, optimization, names = p.stdout.strip().splitlines()[-4:]
     assert ours.startswith(PKG) and utils.startswith(PKG) and optimization.startswith(ref_loader.REFERENCE_ROOT)
-    assert names.split() == ["vilbert.utils", "vilbert._reference_utils", "vilbert._reference_utils"]
+    # the reference's classes and functions carry the module name they have upstream (pickle records it)
+    assert names.split() == ["vilbert.utils", "vilbert.utils", "vilbert.utils"]
+
+
+@needs_reference
+def test_resume_checkpoint_objects_pickle_under_the_upstream_module_path(tmp_path):
+    """train_tasks.py:623-636 pickles `tbLogger` / `MultiTaskStopOnPlateau` objects into the resume checkpoint. The class
+    path pickle records must be the reference's own (`vilbert.utils.<name>`), so that a checkpoint written through this
+    package loads in the upstream code base and vice versa (round-4 advisor finding)."""
+    code = """
+import sys, os, pickle, pickletools
+sys.path.insert(0, %r)
+os.environ['VILBERT_REFERENCE_ROOT'] = %r
+import vilbert.utils as u
+stop = u.MultiTaskStopOnPlateau(mode='max', patience=1, continue_threshold=0.005, cooldown=1, threshold=0.001)
+blob = pickle.dumps({'task_stop_controller': {'TASK1': stop}})
+ops = [(op.name, arg) for op, arg, _ in pickletools.genops(blob)]
+mods = [a for n, a in ops if n in ('GLOBAL', 'STACK_GLOBAL', 'SHORT_BINUNICODE', 'BINUNICODE') and isinstance(a, str) and 'vilbert' in a]
+print('MODS', sorted(set(mods)))
+back = pickle.loads(blob)['task_stop_controller']['TASK1']
+print('SAME', type(back) is u.MultiTaskStopOnPlateau, back.patience, type(back).__module__)
+""" % (PKG, ref_loader.REFERENCE_ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=_env(), cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "MODS ['vilbert.utils']" in p.stdout, p.stdout
+    assert "SAME True 1 vilbert.utils" in p.stdout, p.stdout
 
 
 def test_without_a_reference_checkout_the_package_stands_alone():

@@ -247,11 +247,13 @@ def set_gemm_tile(code):
     return lib().vb_set_gemm_tile(int(code))
 
 
-# "ws": device index -> the workspace registered for that device; "retired": workspaces that were replaced or switched
-# off. They are kept for the life of the process on purpose: a HIP graph captured while one was registered has its address
-# and the stream -> slice assignment baked in (vilbert/graphed.py), and a replay after `set_deterministic(False)` or after
-# a re-registration with a larger size must still write into live memory that nothing else uses.
-_DET = {"ws": {}, "retired": [], "wanted": os.environ.get("VB_DETERMINISTIC", "1") != "0", "mb": 2048}
+# "ws": device index -> the workspace registered for that device; "parked": device index -> the workspace that was
+# registered when the setting was switched off - re-enabling re-registers the SAME tensor (an off / on toggle, e.g. the
+# bench's --deterministic A/B or a test fixture, costs no new 2 GiB allocation). A workspace that is REPLACED by a larger
+# one is dropped: a HIP graph captured while it was registered has its address and the stream -> slice assignment baked
+# in, which is why GraphedTrainStep holds its own reference (`_det_workspace`, vilbert/graphed.py) - the memory stays live
+# exactly as long as something can still write into it.
+_DET = {"ws": {}, "parked": {}, "wanted": os.environ.get("VB_DETERMINISTIC", "1") != "0", "mb": 2048}
 
 
 def set_deterministic(on, workspace_mb=None, device=None):
@@ -272,7 +274,7 @@ def set_deterministic(on, workspace_mb=None, device=None):
         _register_workspace(torch.device(device or "cuda"))
         return bool(prev)
     prev = lib().vb_set_deterministic(0, None, 0)
-    _DET["retired"].extend(_DET["ws"].values())
+    _DET["parked"].update(_DET["ws"])
     _DET["ws"], _DET["wanted"] = {}, False
     return bool(prev)
 
@@ -281,9 +283,9 @@ def _register_workspace(device):
     import torch
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ws = _DET["ws"].get(idx)
+    if ws is None:
+        ws = _DET["parked"].pop(idx, None)          # switched off earlier: the same buffer again
     if ws is None or ws.numel() * 4 < _DET["mb"] * (1 << 20):
-        if ws is not None:
-            _DET["retired"].append(ws)
         ws = torch.empty(_DET["mb"] * (1 << 20) // 4, dtype=torch.float32, device=torch.device("cuda", idx))
     rc = lib().vb_set_deterministic(1, ws.data_ptr(), ws.numel() * 4)
     if rc < 0:

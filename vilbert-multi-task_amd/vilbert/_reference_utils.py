@@ -18,5 +18,13 @@ if not _dir or not _os.path.isfile(_os.path.join(_dir, "utils.py")):
                       "PreTrainedModel on its own; tbLogger / MultiTaskStopOnPlateau / cached_path live in the reference")
 _compat.install()                                # boto3 / botocore / tensorboardX / torch._six import names
 __file__ = _os.path.join(_dir, "utils.py")
-with open(__file__, "r", encoding="utf-8") as _f:
-    exec(compile(_f.read(), __file__, "exec"), globals())
+# The source runs with __name__ = "vilbert.utils" - the name it has in the reference - so that its classes record
+# `__module__ = "vilbert.utils"`: train_tasks.py:623-636 pickles `tbLogger` / `MultiTaskStopOnPlateau` objects into the
+# resume checkpoint, and pickle stores the class as (module, name). "vilbert.utils.tbLogger" resolves in BOTH code bases
+# (here through vilbert.utils.__getattr__ to this very object), so resume checkpoints are interchangeable with upstream.
+_own_name, __name__ = __name__, "vilbert.utils"
+try:
+    with open(__file__, "r", encoding="utf-8") as _f:
+        exec(compile(_f.read(), __file__, "exec"), globals())
+finally:
+    __name__ = _own_name
