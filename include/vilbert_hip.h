@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 14
+#define VB_ABI_VERSION 15
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -544,6 +544,90 @@ typedef struct {
 } vb_concap_batch;
 
 int vb_concap_finish_batch(void* stream, const vb_concap_batch* a);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 TRAINING path (round 5; csrc/gemm_bf16.hip, rowops16.hip, attention.hip). Replaces the reference's reduced-precision
+ * training mode - `model.half()` + apex FP16_Optimizer, /root/reference/train_concap.py:443-461,504-505 (train_tasks.py has
+ * the same block) - the way gfx950 wants it: bf16 activations / saved tensors / activation gradients in HBM (no loss scaling:
+ * bf16 has fp32's exponent range), v_mfma_f32_32x32x16_bf16 products with fp32 accumulation, fp32 LayerNorm statistics and
+ * softmax, fp32 master weights updated by vb_adamw_step with fp32 gradients accumulated straight into the gradient arena,
+ * and a bf16 shadow of every weight - row-major for the forward, transposed for the dgrad - refreshed after each optimizer
+ * step (vb_weight_shadow_bf16). All bf16 arguments are bit patterns (uint16_t), leading dimensions in ELEMENTS.
+ *
+ * vb_linear_bf16:  C[M][N] = epilogue(A[M][K] W[N][K]^T), both operands contraction-contiguous. Forward: W = the shadow of
+ *   nn.Linear.weight (stacked segments are stacked in the shadow). Input gradient: A = dY [M][N'], W = the TRANSPOSED shadow
+ *   [K'][N'] -> dX [M][K'] (the same kernel). K % 64 == 0, N % 128 == 0; A / W 16-byte aligned, lda / ldw % 8 == 0.
+ *   v = acc + bias[n] (bias fp32 or NULL), then exactly one of:
+ *     act = GELU: gelu(v) (vilbert.py:111-117), and gelu'(v) to act_grad if given (bf16 [M][N]);  act = RELU: max(v, 0);
+ *     residual (bf16 [M][N]):  dropout(v, dropout_p, seed) + residual   (mask element index = m * N + n, rng.h - the
+ *         index vb_layernorm_bwd_bf16 regenerates it from; dropout only together with a residual);
+ *     mul (bf16 [M][N]):       v * mul   (dgrad through an activation whose derivative the forward saved);
+ *   written as bf16 to C (ldc % 2 == 0) or as fp32 to C32 (plain / residual / RELU only). Rows >= M are never stored.
+ * vb_wgrad_bf16:   dW_s[seg_n][K] += dY[:, s seg_n : (s + 1) seg_n]^T X   for the nseg stacked segments of dY [M][nseg seg_n]
+ *   (contraction over the M rows: row-major tiles in LDS, fragments by the transposing LDS read ds_read_b64_tr_b16), fp32
+ *   atomics into dW (the gradient-arena slices: zero-filled once per backward pass, or holding an earlier contribution).
+ *   seg_n % 256 == 0, K % 128 == 0, any M; dY / X 16-byte aligned, ldy / ldx % 8 == 0.
+ * vb_colsum_bf16:  out[c] += sum_m x[m][c] (the bias gradient of the same dY), two deterministic stages through `workspace`
+ *   (vb_colsum_bf16_workspace(cols) floats). cols % 4 == 0.
+ * vb_weight_shadow_bf16: w fp32 [rows][cols] (ldw) -> w16 bf16 [rows][cols] (ld16; may be NULL) and wt16 = its transpose
+ *   [cols][rows] (ldt; may be NULL), round to nearest even. rows, cols % 64 == 0. Stacked segments: call once per segment with
+ *   w16 / wt16 offset to the segment's rows / columns.
+ * vb_cast_f32_bf16 / vb_cast_bf16_f32: n elements, round to nearest even / exact; pointers 16-byte aligned.
+ * vb_layernorm_fwd_bf16 / vb_layernorm_bwd_bf16: BertLayerNorm (vilbert.py:313-317) and its autograd on bf16 rows - the
+ *   statistics (saved as fp32 mean / rstd per row), the normalisation and the gradient sums in fp32 as vb_layernorm_fwd /
+ *   vb_layernorm_bwd; dgamma / dbeta fp32, OVERWRITTEN (two deterministic stages through `workspace` =
+ *   vb_layernorm_bwd_bf16_workspace(rows, n_cols) floats); dx_dropped (optional, with 0 < dropout_p < 1): dx under the
+ *   dropout mask (seed, row * n_cols + col) of the dense layer in front, written in the same pass. n_cols % 4 == 0, <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const uint16_t* A;
+    int64_t lda;
+    const uint16_t* W;
+    int64_t ldw;
+    const float* bias;          /* [N] or NULL */
+    uint16_t* C;                /* bf16 out, or NULL */
+    int64_t ldc;
+    float* C32;                 /* fp32 out, or NULL (exactly one of C / C32) */
+    int64_t ldc32;
+    const uint16_t* residual;   /* or NULL */
+    int64_t ldr;
+    const uint16_t* mul;        /* or NULL (at most one of residual / mul) */
+    int64_t ldm;
+    uint16_t* act_grad;         /* GELU only: gelu'(v) out, or NULL */
+    int64_t ldg;
+    int64_t M, N, K;
+    int32_t act;                /* VB_ACT_NONE | VB_ACT_GELU | VB_ACT_RELU */
+    float dropout_p;
+    uint64_t seed;
+} vb_linear_bf16_args;
+
+int vb_linear_bf16(void* stream, const vb_linear_bf16_args* a);
+
+typedef struct {
+    const uint16_t* dY;
+    int64_t ldy;
+    const uint16_t* X;
+    int64_t ldx;
+    float* dW[VB_MAX_SEGMENTS];
+    int64_t ldw;
+    int64_t M, K;
+    int32_t nseg, seg_n;
+} vb_wgrad_bf16_args;
+
+int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a);
+
+int64_t vb_colsum_bf16_workspace(int32_t cols);
+int vb_colsum_bf16(void* stream, int64_t rows, int32_t cols, const uint16_t* x, int64_t ldx, float* out, float* workspace);
+int vb_weight_shadow_bf16(void* stream, int32_t rows, int32_t cols, const float* w, int64_t ldw, uint16_t* w16, int64_t ld16,
+                          uint16_t* wt16, int64_t ldt);
+int vb_cast_f32_bf16(void* stream, int64_t n, const float* x, uint16_t* y);
+int vb_cast_bf16_f32(void* stream, int64_t n, const uint16_t* x, float* y);
+int vb_layernorm_fwd_bf16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* x, const float* gamma, const float* beta,
+                          float eps, uint16_t* y, float* mean, float* rstd);
+int64_t vb_layernorm_bwd_bf16_workspace(int64_t rows, int32_t n_cols);
+int vb_layernorm_bwd_bf16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* dy, const uint16_t* x, const float* mean,
+                          const float* rstd, const float* gamma, uint16_t* dx, float* dgamma, float* dbeta, float* workspace,
+                          uint16_t* dx_dropped, float dropout_p, uint64_t seed);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,801 @@
+// bf16 TRAINING path, round 5: the reduced-precision mode the reference reaches with `model.half()` + apex FP16_Optimizer
+// (/root/reference/train_concap.py:443-461,504-505), re-designed for gfx950 as bf16 tensors in HBM + fp32 master weights:
+// activations, saved tensors and activation gradients are bf16 (2 bytes per element through HBM and LDS), every product runs
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, weight gradients are accumulated in fp32 straight into the gradient
+// arena, AdamW keeps updating fp32 parameters, and a bf16 shadow of every weight (row-major AND transposed) is refreshed once
+// per optimizer step.
+//
+//   gemm_bf16_kernel   C[M, N] = epilogue(A[M, K] W[N, K]^T)      forward (W = the shadow) and dgrad (dX = dY Wt^T with the
+//                      TRANSPOSED shadow Wt[K, N] as the "weight": the same kernel, both operands contraction-contiguous)
+//   wgrad_bf16_kernel  dW[N, K] += dY[M, N]^T X[M, K]              contraction over the ROWS of both operands: the tiles land
+//                      in LDS row-major (LDS-DMA) and the MFMA fragments are fetched with ds_read_b64_tr_b16, gfx950's
+//                      transposing LDS read (4 x 16 block per 16 lanes -> each lane 4 consecutive rows of one column)
+//   weight_shadow_kernel, cast kernels, colsum (bias gradient)
+//
+// Both GEMM kernels are the persistent skeleton of mx8.hip (its byte geometry is identical: a K tile of 64 bf16 = 128 bytes
+// per row): ONE block per CU = 8 MFMA waves in a 4 x 2 grid (wave tile 64 x 64 = 2 x 2 MFMA tiles of 32 x 32, block tile
+// 256 x 128) + 2 loader waves that only issue LDS-DMA (global_load_lds_dwordx4, 1 KiB each: 32 for the A tile, 16 for the W
+// tile per K tile); 3-stage ring of 48 KiB; the K tiles of ALL output tiles of a block form one stream (the next tile's
+// operands land under the epilogue); ONE barrier per K tile. A K tile = four MFMA steps (K = 16 each) on two static fragment
+// register sets: step s multiplies set s & 1 while set (s + 1) & 1 is read from LDS; the barrier sits between steps 2 and 3,
+// after the last read of the stage.
+#include "gemm_core.h"
+#include <type_traits>
+
+namespace {
+
+using namespace vbgemm;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int HB_BM = 256, HB_BN = 128, HB_BK = 64, HB_S = 3;
+constexpr int HB_ROWB = 2 * HB_BK;              // bytes of one tile row (NT kernel): 128
+constexpr int HB_A = HB_BM * HB_ROWB;           // 32,768 bytes
+constexpr int HB_B = HB_BN * HB_ROWB;           // 16,384
+constexpr int HB_STAGE = HB_A + HB_B;           // 49,152
+constexpr int HB_LDS = HB_S * HB_STAGE;         // 147,456
+constexpr int HB_MFMA_WAVES = 8, HB_THREADS = 64 * (HB_MFMA_WAVES + 2);
+
+__device__ __forceinline__ unsigned short bf16_rne(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)bf16_rne(lo) | ((unsigned)bf16_rne(hi) << 16); }
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// one LDS-DMA: LDS[lds + 16 lane] <- *(base + off[lane]), wave-uniform 64-bit base + per-lane 32-bit byte offset
+__device__ __forceinline__ void hb_glds16(unsigned off, const void* base, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void hb_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// tile of block `b` in round `it`: the 32 blocks of an XCD (b % 8) work on a 4 x 8 patch of tiles where the tile grid allows
+// it, so that they share A / W panels in their L2 (mx8.hip: mx_tile_of / mx_origin)
+__device__ __forceinline__ int hb_tile_of(int b, int it, int grid, int tiles) {
+    const int base = it * grid;
+    const int n = min(grid, tiles - base);
+    if (n <= 0) return -1;
+    if ((n & 7) != 0) return b < n ? base + b : -1;
+    const int per = n >> 3, x = b & 7, j = b >> 3;
+    return j < per ? base + x * per + j : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT kernel
+// ---------------------------------------------------------------------------------------------------------------
+// EPI (compile time): what happens to v = acc + bias before it is stored
+enum { HB_PLAIN = 0,   // v
+       HB_GELU = 1,    // gelu(v), and gelu'(v) to D (the derivative the dgrad epilogue multiplies by - no erf in backward)
+       HB_RES = 2,     // v + R
+       HB_DROPRES = 3, // dropout(v) + R
+       HB_MUL = 4,     // v * MUL            (dgrad through an activation: MUL = the saved derivative)
+       HB_RELU = 5 };  // max(v, 0)
+enum { HB_OUT_BF16 = 0, HB_OUT_F32 = 1 };
+
+struct HbP {
+    int M, N, K;
+    const unsigned short* A; long lda;     // elements
+    const unsigned short* B; long ldb;
+    const float* bias;
+    const unsigned short* R; long ldr;     // residual or multiplier, bf16 [M, N]
+    unsigned short* C; long ldc;
+    float* C32; long ldc32;
+    unsigned short* D; long ldd;           // gelu'(pre) out (HB_GELU), may be null
+    int tiles_n, tiles;
+    float drop_p, drop_scale;
+    uint64_t seed;
+    const uint64_t* epoch;
+};
+
+__device__ __forceinline__ bool hb_origin(const HbP& p, int b, int it, int grid, int& m0, int& n0) {
+    const int t = hb_tile_of(b, it, grid, p.tiles);
+    if (t < 0) return false;
+    const int tiles_m = p.tiles / p.tiles_n;
+    int r, c;
+    if ((p.tiles_n & 7) == 0 && (tiles_m & 3) == 0) {
+        const int patch = t >> 5, w = t & 31, pcols = p.tiles_n >> 3;
+        r = (patch / pcols) * 4 + (w >> 3);
+        c = (patch % pcols) * 8 + (w & 7);
+    } else {
+        r = t / p.tiles_n;
+        c = t % p.tiles_n;
+    }
+    m0 = r * HB_BM;
+    n0 = c * HB_BN;
+    return true;
+}
+
+// Loader wave of one operand of the NT kernel: ND DMAs (8 tile rows of 128 bytes each) per K tile. LDS rows of 128 bytes,
+// the eight 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 (fragment ds_read_b128 conflict-free); the DMA writes
+// lane-linear, so the swizzle is applied on the SOURCE address. PERM (the W operand): LDS row 64 w + 32 j + k of the tile
+// holds W row 64 w + 2 k + j, so that lane k of the natural accumulator map owns the ADJACENT output columns 2 k, 2 k + 1.
+template <int ND, bool IS_A>
+__device__ __forceinline__ void hb_loader(const HbP& p, const unsigned lds0, const int lane, const int nk, const int rounds) {
+    const unsigned short* const mat = IS_A ? p.A : p.B;
+    const long ld = IS_A ? p.lda : p.ldb;
+    const int nrows = IS_A ? p.M : p.N;
+    constexpr unsigned REG = IS_A ? 0u : (unsigned)HB_A;
+    static_assert(ND <= 63, "vmcnt is a 6-bit counter");
+    unsigned off[ND];
+    const unsigned short* base = nullptr;
+    auto set_tile = [&](int round) {
+        int m0 = 0, n0 = 0;
+        hb_origin(p, blockIdx.x, round, gridDim.x, m0, n0);
+        const int r0 = IS_A ? m0 : n0;
+        base = mat + (long)r0 * ld;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int row = 8 * i + (lane >> 3), slot = lane & 7;     // LDS row of this lane's 16 bytes
+            const int chunk = slot ^ ((row >> 1) & 7);
+            const int grow = IS_A ? row : (row & 64) + 2 * (row & 31) + ((row >> 5) & 1);   // matrix row it holds
+            off[i] = (unsigned)((long)min(grow, nrows - 1 - r0) * ld * 2 + 16 * chunk);    // rows past the matrix: clamped, never stored
+        }
+    };
+    int it = 0, kt = 0, stage_w = 0;
+    auto issue_next = [&]() {
+        const unsigned l = lds0 + (unsigned)stage_w * HB_STAGE;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) hb_glds16(off[i], base, l + REG + 1024u * i);
+        base += HB_BK;
+        stage_w = stage_w == HB_S - 1 ? 0 : stage_w + 1;
+        if (++kt == nk) {
+            kt = 0;
+            ++it;
+            if (it < rounds) set_tile(it);
+        }
+    };
+    const int total = rounds * nk;
+    set_tile(0);
+    __builtin_amdgcn_s_setprio(2);
+    for (int s = 0; s < HB_S && s < total; ++s) issue_next();
+    if (total >= 2) hb_wait_vm<ND>(); else hb_wait_vm<0>();     // K tile 0 has landed (at most the newest tile is pending)
+    __builtin_amdgcn_s_barrier();                                 // P0
+    for (int g = 0; g < total; ++g) {
+        // K tile g + 1 has landed: issued so far = min(total, g + 3) tiles, so at most tile g + 2 may be pending
+        if (g + 3 <= total) hb_wait_vm<ND>(); else hb_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                             // B_g: stage g has been read completely
+        if (g + 3 < total) issue_next();
+    }
+}
+
+template <int OUT, int EPI>
+__global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nk = p.K / HB_BK;
+    const int b = blockIdx.x, grid = gridDim.x;
+    int rounds = 0;
+    while (rounds * grid < p.tiles && hb_tile_of(b, rounds, grid, p.tiles) >= 0) ++rounds;
+    if (rounds == 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= HB_MFMA_WAVES) {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+        if (wave == HB_MFMA_WAVES) hb_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, nk, rounds);
+        else hb_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, nk, rounds);
+        return;
+    }
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int key = (l31 >> 1) & 7;
+    const int fa_off = (wm * 64 + l31) * HB_ROWB, fb_off = HB_A + (wn * 64 + l31) * HB_ROWB;
+
+    f32x16 acc[2][2];
+    bf16x8 fa[2][2], fb[2][2];          // [register set][tile]
+
+    // v_mfma_f32_32x32x16_bf16: lane (l31, hi) supplies 8 contraction elements of row / column l31 - the 16 bytes of chunk
+    // 2 s + hi of the tile row for step s. Both operands are fetched with the same (lane, element) -> k map, so the order in
+    // which the instruction consumes its 16 k values cannot matter.
+    auto read_set = [&](auto S_, const char* stage, int s) {
+        constexpr int S = decltype(S_)::value;
+        const int co = ((2 * s + hi) ^ key) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[S][i] = *reinterpret_cast<const bf16x8*>(stage + fa_off + i * 32 * HB_ROWB + co);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[S][j] = *reinterpret_cast<const bf16x8*>(stage + fb_off + j * 32 * HB_ROWB + co);
+    };
+    auto mfmas = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                // natural product: rows of the A fragment -> accumulator registers, rows of the W fragment -> lane & 31
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    __builtin_amdgcn_s_barrier();   // P0: K tile 0 has landed
+    int st = 0;                     // ring stage of the current K tile
+    for (int it = 0; it < rounds; ++it) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        read_set(I0{}, smem + st * HB_STAGE, 0);   // first step of this output tile (landed before the previous barrier)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const char* cur = smem + st * HB_STAGE;
+            st = st == HB_S - 1 ? 0 : st + 1;
+            const char* nxt = smem + st * HB_STAGE;
+            read_set(I1{}, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);   // the LDS reads go out first, the MFMAs cover their latency
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I0{}, cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I1{}, cur, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // B_g: every read of stage g is complete
+            read_set(I0{}, nxt, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {   // last K tile of this output tile: no successor to prefetch (the next output tile reads its first step above, so
+            // that no fragment register is live across the epilogue)
+            const char* cur = smem + st * HB_STAGE;
+            st = st == HB_S - 1 ? 0 : st + 1;
+            read_set(I1{}, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I0{}, cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I1{}, cur, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            mfmas(I1{});
+        }
+        int m0 = 0, n0 = 0;
+        hb_origin(p, b, it, grid, m0, n0);
+        // ---- natural map: acc[i][j][r] = row m0 + wm 64 + 32 i + 4 hi + (r & 3) + 8 (r >> 2), column n0 + wn 64 + 2 l31 + j
+        const int col = n0 + wn * 64 + 2 * l31;
+        float2 bv = float2{0.f, 0.f};
+        if (p.bias != nullptr) bv = *reinterpret_cast<const float2*>(p.bias + col);
+        const bool full = m0 + HB_BM <= p.M;
+        const uint64_t seed = EPI == HB_DROPRES ? vb_seed_with_epoch(p.seed, p.epoch) : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = m0 + wm * 64 + 32 * i + 4 * hi;
+            unsigned rw[16];
+            if (EPI == HB_RES || EPI == HB_DROPRES || EPI == HB_MUL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)   // clamped, never predicated (a per-element branch serialises the loads)
+                    rw[r] = *reinterpret_cast<const unsigned*>(p.R + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col);
+            }
+            float2 v[16], d[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = float2{acc[i][0][r] + bv.x, acc[i][1][r] + bv.y};
+                if (EPI == HB_GELU) {
+                    gelu_and_grad(v[r].x, v[r].x, d[r].x);
+                    gelu_and_grad(v[r].y, v[r].y, d[r].y);
+                }
+                if (EPI == HB_RELU) v[r] = float2{fmaxf(v[r].x, 0.f), fmaxf(v[r].y, 0.f)};
+                if (EPI == HB_DROPRES) {
+                    const uint64_t idx = (uint64_t)((long)(rbase + (r & 3) + 8 * (r >> 2)) * p.N + col);
+                    v[r].x = vb_keep(seed, idx, p.drop_p) ? v[r].x * p.drop_scale : 0.f;
+                    v[r].y = vb_keep(seed, idx + 1, p.drop_p) ? v[r].y * p.drop_scale : 0.f;
+                }
+                if (EPI == HB_RES || EPI == HB_DROPRES) v[r] = float2{v[r].x + bf16_lo(rw[r]), v[r].y + bf16_hi(rw[r])};
+                if (EPI == HB_MUL) v[r] = float2{v[r].x * bf16_lo(rw[r]), v[r].y * bf16_hi(rw[r])};
+            }
+            if (OUT == HB_OUT_F32) {
+                float* __restrict__ cp = p.C32 + (long)rbase * p.ldc32 + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (full || rbase + (r & 3) + 8 * (r >> 2) < p.M)
+                        *reinterpret_cast<float2*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc32) = v[r];
+            } else {
+                unsigned short* __restrict__ cp = p.C + (long)rbase * p.ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (full || rbase + (r & 3) + 8 * (r >> 2) < p.M)
+                        *reinterpret_cast<unsigned*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc) = pack_bf16(v[r].x, v[r].y);
+            }
+            if (EPI == HB_GELU) {
+                if (p.D != nullptr) {
+                    unsigned short* __restrict__ dp = p.D + (long)rbase * p.ldd + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (full || rbase + (r & 3) + 8 * (r >> 2) < p.M)
+                            *reinterpret_cast<unsigned*>(dp + (long)((r & 3) + 8 * (r >> 2)) * p.ldd) = pack_bf16(d[r].x, d[r].y);
+                }
+            }
+        }
+    }
+}
+
+template <int OUT, int EPI>
+int launch_hb(hipStream_t st, const HbP& p) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<OUT, EPI>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    const int grid = p.tiles < 256 ? p.tiles : 256;
+    hipLaunchKernelGGL((gemm_bf16_kernel<OUT, EPI>), dim3(grid), dim3(HB_THREADS), HB_LDS, st, p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TN kernel (weight gradient): dW[n, k] += sum_m dY[m, n] X[m, k]
+// ---------------------------------------------------------------------------------------------------------------
+// Output tile 256 (n) x 128 (k), contraction tile 64 rows of m. Both operand tiles land in LDS ROW-major as the DMA
+// delivers them - [64 m][256 n] (512-byte rows) and [64 m][128 k] (256-byte rows) - and the MFMA fragments (8 consecutive
+// m for one n / k per lane) are fetched with ds_read_b64_tr_b16: the 16 lanes of a group read a 4 (m) x 16 (n) block,
+// lane 4 r + q supplying the address of row r, columns 4 q .. 4 q + 3, and lane i receives column i of the block = 4
+// consecutive m. Two such reads (m = 8 hi + 4 t + 0..3, t = 0, 1) make one operand register set; A and B use the same
+// (lane, element) -> m map, so the instruction's internal order of its 16 contraction values cannot matter.
+// Bank conflicts: the 32 lanes of a half-wave read 4 rows x 64 bytes; rows are 2 (A) / 1 (B) whole 256-byte bank rows
+// apart, so the 16-byte chunks of tile row m are stored XORed with (m & 3) << 2 (again on the DMA's SOURCE side): the four
+// rows of a read fall into the four different 64-byte quarters of the bank row.
+// Work unit = (output tile, contraction split); the units are dealt to the persistent blocks round-robin, all tiles of
+// one split first (the 256 concurrent units then share the same m range of dY and X in L2). Partial sums are ADDED to dW
+// with fp32 atomics (the gradient arena is zero-filled once per backward pass).
+constexpr int HW_ROWA = 2 * HB_BM;   // 512 bytes: one m row of the dY tile (256 n)
+constexpr int HW_ROWB = 2 * HB_BN;   // 256 bytes: one m row of the X tile (128 k)
+
+struct HwP {
+    int M, N, K;
+    const unsigned short* Y; long ldy;
+    const unsigned short* X; long ldx;
+    float* C[VB_MAX_SEGMENTS]; long ldc; int cseg;
+    int tiles_k, tiles;             // tiles = (N / 256) (K / 128)
+    int nkt, kt_per_split, splits;  // contraction tiles in total / per unit, units per tile
+    int units;
+};
+
+__device__ __forceinline__ void hw_unit(const HwP& p, int u, int& n0, int& k0, int& kt0, int& nk) {
+    const int split = u / p.tiles, t = u - split * p.tiles;
+    n0 = (t / p.tiles_k) * HB_BM;
+    k0 = (t % p.tiles_k) * HB_BN;
+    kt0 = split * p.kt_per_split;
+    nk = min(p.kt_per_split, p.nkt - kt0);
+}
+
+template <int ND, bool IS_A>
+__device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, const int lane, const int n_units) {
+    const unsigned short* const mat = IS_A ? p.Y : p.X;
+    const long ld = IS_A ? p.ldy : p.ldx;
+    constexpr unsigned REG = IS_A ? 0u : (unsigned)HB_A;
+    constexpr int RPD = IS_A ? 2 : 4;              // tile rows per DMA
+    constexpr int CPR = IS_A ? 32 : 16;            // 16-byte chunks per tile row
+    unsigned off[ND];
+    const int sub = lane / CPR, cp = lane % CPR;   // row inside the DMA's rows, physical chunk
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int m = RPD * i + sub;
+        off[i] = (unsigned)((long)m * ld * 2 + 16 * (cp ^ ((m & 3) << 2)));
+    }
+    const unsigned short* base = nullptr;
+    int u_idx = 0, kt = 0, nk = 0, kt0 = 0, stage_w = 0;
+    long total = 0;
+    for (int i = 0; i < n_units; ++i) {
+        int n0, k0, a, c;
+        hw_unit(p, blockIdx.x + i * gridDim.x, n0, k0, a, c);
+        total += c;
+    }
+    auto set_unit = [&](int i) {
+        int n0, k0;
+        hw_unit(p, blockIdx.x + i * gridDim.x, n0, k0, kt0, nk);
+        base = mat + (long)kt0 * HB_BK * ld + (IS_A ? n0 : k0);
+        kt = 0;
+    };
+    auto issue_next = [&]() {
+        const unsigned l = lds0 + (unsigned)stage_w * HB_STAGE;
+        const int rows_left = p.M - (kt0 + kt) * HB_BK;
+        if (rows_left >= HB_BK) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) hb_glds16(off[i], base, l + REG + 1024u * i);
+        } else {
+            // the last contraction tile of a ragged M: rows past the end are fetched from the last real row (finite
+            // data; the MFMA waves zero the dY fragment elements of those rows)
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const int m = RPD * i + sub;
+                const unsigned o = (unsigned)((long)min(m, rows_left - 1) * ld * 2 + 16 * (cp ^ ((m & 3) << 2)));
+                hb_glds16(o, base, l + REG + 1024u * i);
+            }
+        }
+        base += (long)HB_BK * ld;
+        stage_w = stage_w == HB_S - 1 ? 0 : stage_w + 1;
+        if (++kt == nk) {
+            ++u_idx;
+            if (u_idx < n_units) set_unit(u_idx);
+        }
+    };
+    set_unit(0);
+    __builtin_amdgcn_s_setprio(2);
+    for (int s = 0; s < HB_S && s < total; ++s) issue_next();
+    if (total >= 2) hb_wait_vm<ND>(); else hb_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                                 // P0
+    for (long g = 0; g < total; ++g) {
+        if (g + 3 <= total) hb_wait_vm<ND>(); else hb_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                             // B_g
+        if (g + 3 < total) issue_next();
+    }
+}
+
+__global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, grid = gridDim.x;
+    const int n_units = (p.units - b + grid - 1) / grid;
+    if (n_units <= 0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= HB_MFMA_WAVES) {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+        if (wave == HB_MFMA_WAVES) hw_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, n_units);
+        else hw_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, n_units);
+        return;
+    }
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;          // wave tile: n rows wm 64 .., k columns wn 64 ..
+    // transposing read: lane = 16 g4 + 4 r + q reads row (8 hi + 4 t + r) of the step, columns 16 nb + 4 q .. + 3
+    const int r = (lane >> 2) & 3, q = lane & 3, nb = (lane >> 4) & 1;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned a_addr[2], b_addr[2];                    // byte address inside a stage of (step 0, t = 0) for MFMA tile i / j
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ca = wm * 8 + 4 * i + 2 * nb + (q >> 1);
+        a_addr[i] = (unsigned)((8 * hi + r) * HW_ROWA + ((ca ^ (r << 2)) << 4) + (q & 1) * 8);
+        const int cb = wn * 8 + 4 * i + 2 * nb + (q >> 1);
+        b_addr[i] = (unsigned)(HB_A + (8 * hi + r) * HW_ROWB + ((cb ^ (r << 2)) << 4) + (q & 1) * 8);
+    }
+
+    f32x16 acc[2][2];
+    bf16x8 fa[2][2], fb[2][2];
+    auto tr = [&](unsigned addr) -> bf16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<lds_bf16x4*>(addr));
+    };
+    auto read_set = [&](auto S_, unsigned stage, int s) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x4 lo = tr(stage + a_addr[i] + (unsigned)(16 * s) * HW_ROWA);
+            const bf16x4 up = tr(stage + a_addr[i] + (unsigned)(16 * s + 4) * HW_ROWA);
+            fa[S][i] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x4 lo = tr(stage + b_addr[j] + (unsigned)(16 * s) * HW_ROWB);
+            const bf16x4 up = tr(stage + b_addr[j] + (unsigned)(16 * s + 4) * HW_ROWB);
+            fb[S][j] = __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    // ragged M: zero the dY fragment elements whose row is past the end (element e of the set = row 16 s + 8 hi + 4 (e >> 2)
+    // + (e & 3) of the contraction tile); the X side then multiplies finite values by exact zeros
+    auto mask_set = [&](auto S_, int s, int rows_left) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v4i w = __builtin_bit_cast(v4i, fa[S][i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = 16 * s + 8 * hi + 4 * (e >> 2) + (e & 3);
+                if (m >= rows_left) w[e >> 1] &= (e & 1) ? 0x0000ffff : 0xffff0000;
+            }
+            fa[S][i] = __builtin_bit_cast(bf16x8, w);
+        }
+    };
+    auto mfmas = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    __builtin_amdgcn_s_barrier();   // P0
+    int st = 0;
+    for (int ui = 0; ui < n_units; ++ui) {
+        int n0, k0, kt0, nk;
+        hw_unit(p, b + ui * grid, n0, k0, kt0, nk);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
+        // rows of the LAST contraction tile of this unit that exist (64 = all)
+        const int last_rows = min(HB_BK, p.M - (kt0 + nk - 1) * HB_BK);
+        const bool ragged = last_rows < HB_BK;
+        read_set(I0{}, lds_base + st * HB_STAGE, 0);
+        if (ragged && nk == 1) mask_set(I0{}, 0, last_rows);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const unsigned cur = lds_base + st * HB_STAGE;
+            st = st == HB_S - 1 ? 0 : st + 1;
+            const unsigned nxt = lds_base + st * HB_STAGE;
+            read_set(I1{}, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I0{}, cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I1{}, cur, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            read_set(I0{}, nxt, 0);
+            if (ragged && kt + 2 == nk) mask_set(I0{}, 0, last_rows);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const unsigned cur = lds_base + st * HB_STAGE;
+            st = st == HB_S - 1 ? 0 : st + 1;
+            read_set(I1{}, cur, 1);
+            if (ragged) mask_set(I1{}, 1, last_rows);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I0{}, cur, 2);
+            if (ragged) mask_set(I0{}, 2, last_rows);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_set(I1{}, cur, 3);
+            if (ragged) mask_set(I1{}, 3, last_rows);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            mfmas(I1{});
+        }
+        // acc[i][j][rr]: n = n0 + wm 64 + 32 i + 4 hi + (rr & 3) + 8 (rr >> 2), k = k0 + wn 64 + 32 j + l31
+        const int seg = n0 / p.cseg;
+        float* __restrict__ cb = p.C[seg] + (long)(n0 - seg * p.cseg + wm * 64 + 4 * hi) * p.ldc + k0 + wn * 64 + l31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr)
+                    unsafeAtomicAdd(cb + (long)(32 * i + (rr & 3) + 8 * (rr >> 2)) * p.ldc + 32 * j, acc[i][j][rr]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(long n8, const float* __restrict__ x, unsigned short* __restrict__ y,
+                                                            long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + 8 * i), c = *reinterpret_cast<const f32x4*>(x + 8 * i + 4);
+        *reinterpret_cast<v4i*>(y + 8 * i) = v4i{(int)pack_bf16(a[0], a[1]), (int)pack_bf16(a[2], a[3]), (int)pack_bf16(c[0], c[1]),
+                                                 (int)pack_bf16(c[2], c[3])};
+    } else if (i == n8) {
+        for (long e = 8 * n8; e < n; ++e) y[e] = bf16_rne(x[e]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(long n8, const unsigned short* __restrict__ x, float* __restrict__ y,
+                                                            long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n8) {
+        const v4i w = *reinterpret_cast<const v4i*>(x + 8 * i);
+        *reinterpret_cast<f32x4*>(y + 8 * i) = f32x4{bf16_lo(w[0]), bf16_hi(w[0]), bf16_lo(w[1]), bf16_hi(w[1])};
+        *reinterpret_cast<f32x4*>(y + 8 * i + 4) = f32x4{bf16_lo(w[2]), bf16_hi(w[2]), bf16_lo(w[3]), bf16_hi(w[3])};
+    } else if (i == n8) {
+        for (long e = 8 * n8; e < n; ++e) y[e] = __uint_as_float((unsigned)x[e] << 16);
+    }
+}
+
+// fp32 master weight [rows, cols] -> bf16 shadow rows (w16 [rows, ld16]) AND its transpose (wt16 [cols, ldt], written at
+// column offset col_off = the row offset of this segment inside a stacked weight); 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void weight_shadow_kernel(int rows, int cols, const float* __restrict__ w, long ldw,
+                                                            unsigned short* __restrict__ w16, long ld16,
+                                                            unsigned short* __restrict__ wt16, long ldt) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = tr + 16 * i;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + (long)(r0 + row) * ldw + c0 + tc);
+        const unsigned lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        if (w16 != nullptr) *reinterpret_cast<uint2*>(w16 + (long)(r0 + row) * ld16 + c0 + tc) = uint2{lo, hi};
+        tile[row][tc] = (unsigned short)lo; tile[row][tc + 1] = (unsigned short)(lo >> 16);
+        tile[row][tc + 2] = (unsigned short)hi; tile[row][tc + 3] = (unsigned short)(hi >> 16);
+    }
+    __syncthreads();
+    if (wt16 == nullptr) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = tr + 16 * i;      // row of the transposed tile
+        const unsigned lo = (unsigned)tile[tc][col] | ((unsigned)tile[tc + 1][col] << 16);
+        const unsigned hi = (unsigned)tile[tc + 2][col] | ((unsigned)tile[tc + 3][col] << 16);
+        *reinterpret_cast<uint2*>(wt16 + (long)(c0 + col) * ldt + r0 + tc) = uint2{lo, hi};
+    }
+}
+
+// column sums of a bf16 [rows, cols] matrix (bias gradient): stage 1 - a block owns 256 columns x one row slab, a thread 4
+// columns of every fourth row, waves summed through LDS, one partial row per slab; stage 2 - the slabs in order
+// (deterministic). out: ADDED into (the gradient arena semantics of the weight gradients).
+constexpr int CS_SLABS = 64;
+__global__ __launch_bounds__(256) void colsum16_kernel(long rows, int cols, const unsigned short* __restrict__ x, long ldx,
+                                                       float* __restrict__ part) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + 4 * lane;
+    const long per = (rows + CS_SLABS - 1) / CS_SLABS;
+    const long lo = blockIdx.y * per, hi = min(rows, lo + per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < cols)
+        for (long r = lo + wave; r < hi; r += 4) {
+            const uint2 w = *reinterpret_cast<const uint2*>(x + r * ldx + col);
+            s += f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
+        }
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < cols) {
+        s += red[0][lane]; s += red[1][lane]; s += red[2][lane];
+        *reinterpret_cast<f32x4*>(part + (long)blockIdx.y * cols + col) = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum16_finish_kernel(int cols, const float* __restrict__ part, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < CS_SLABS; ++i) s += part[(long)i * cols + c];
+    out[c] += s;
+}
+
+}  // namespace
+
+extern "C" int vb_linear_bf16(void* stream, const vb_linear_bf16_args* a) {
+    if (a == nullptr || a->A == nullptr || a->W == nullptr) return VB_E_BADARG;
+    if ((a->C != nullptr) + (a->C32 != nullptr) != 1) return VB_E_BADARG;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0) return VB_E_BADARG;
+    if (a->K % HB_BK != 0 || a->N % HB_BN != 0) return VB_E_ALIGN;
+    if (a->lda % 8 != 0 || a->ldw % 8 != 0 || a->lda < a->K || a->ldw < a->K || !vb_aligned16(a->A) || !vb_aligned16(a->W))
+        return VB_E_ALIGN;
+    if (a->C != nullptr && (a->ldc % 2 != 0 || a->ldc < a->N || (reinterpret_cast<uintptr_t>(a->C) & 3u) != 0)) return VB_E_ALIGN;
+    if (a->C32 != nullptr && (a->ldc32 % 2 != 0 || a->ldc32 < a->N || (reinterpret_cast<uintptr_t>(a->C32) & 7u) != 0)) return VB_E_ALIGN;
+    if (a->bias != nullptr && (reinterpret_cast<uintptr_t>(a->bias) & 7u) != 0) return VB_E_ALIGN;
+    if (a->residual != nullptr && a->mul != nullptr) return VB_E_BADARG;
+    const uint16_t* second = a->residual != nullptr ? a->residual : a->mul;
+    const int64_t ld2 = a->residual != nullptr ? a->ldr : a->ldm;
+    if (second != nullptr && (ld2 % 2 != 0 || ld2 < a->N || (reinterpret_cast<uintptr_t>(second) & 3u) != 0)) return VB_E_ALIGN;
+    if (a->act_grad != nullptr && (a->ldg % 2 != 0 || a->ldg < a->N || (reinterpret_cast<uintptr_t>(a->act_grad) & 3u) != 0))
+        return VB_E_ALIGN;
+    if (a->act != VB_ACT_NONE && a->act != VB_ACT_GELU && a->act != VB_ACT_RELU) return VB_E_BADARG;
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
+    if (a->lda * 2 * 256 > 0xffffffffL || a->ldw * 2 * 256 > 0xffffffffL) return VB_E_RANGE;
+    const bool drop = a->dropout_p > 0.f;
+    // combinations the model uses; anything else is not built
+    if (a->act != VB_ACT_NONE && (second != nullptr || drop)) return VB_E_BADARG;
+    if (a->act_grad != nullptr && a->act != VB_ACT_GELU) return VB_E_BADARG;
+    if (drop && a->residual == nullptr) return VB_E_BADARG;
+    HbP p{};
+    p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
+    p.A = a->A; p.lda = a->lda; p.B = a->W; p.ldb = a->ldw;
+    p.bias = a->bias;
+    p.R = second; p.ldr = ld2;
+    p.C = a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;
+    p.D = a->act_grad; p.ldd = a->ldg;
+    p.tiles_n = p.N / HB_BN;
+    p.tiles = ((p.M + HB_BM - 1) / HB_BM) * p.tiles_n;
+    p.drop_p = a->dropout_p;
+    p.drop_scale = drop ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
+    p.seed = a->seed;
+    p.epoch = vb_seed_epoch();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a->C32 != nullptr) {
+        if (a->act == VB_ACT_GELU || drop || a->mul != nullptr) return VB_E_BADARG;
+        if (a->act == VB_ACT_RELU) return launch_hb<HB_OUT_F32, HB_RELU>(st, p);
+        return a->residual != nullptr ? launch_hb<HB_OUT_F32, HB_RES>(st, p) : launch_hb<HB_OUT_F32, HB_PLAIN>(st, p);
+    }
+    if (a->act == VB_ACT_GELU) return launch_hb<HB_OUT_BF16, HB_GELU>(st, p);
+    if (a->act == VB_ACT_RELU) return launch_hb<HB_OUT_BF16, HB_RELU>(st, p);
+    if (a->mul != nullptr) return launch_hb<HB_OUT_BF16, HB_MUL>(st, p);
+    if (drop) return launch_hb<HB_OUT_BF16, HB_DROPRES>(st, p);
+    if (a->residual != nullptr) return launch_hb<HB_OUT_BF16, HB_RES>(st, p);
+    return launch_hb<HB_OUT_BF16, HB_PLAIN>(st, p);
+}
+
+extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
+    if (a == nullptr || a->dY == nullptr || a->X == nullptr) return VB_E_BADARG;
+    if (a->M <= 0 || a->K <= 0 || a->nseg <= 0 || a->nseg > VB_MAX_SEGMENTS || a->seg_n <= 0) return VB_E_BADARG;
+    const long N = (long)a->nseg * a->seg_n;
+    if (a->seg_n % HB_BM != 0 || a->K % HB_BN != 0) return VB_E_ALIGN;
+    if (a->ldy % 8 != 0 || a->ldx % 8 != 0 || a->ldy < N || a->ldx < a->K || !vb_aligned16(a->dY) || !vb_aligned16(a->X))
+        return VB_E_ALIGN;
+    if (a->ldw < a->K) return VB_E_ALIGN;
+    if (a->ldy * 2 * 64 > 0xffffffffL || a->ldx * 2 * 64 > 0xffffffffL) return VB_E_RANGE;
+    HwP p{};
+    p.M = (int)a->M; p.N = (int)N; p.K = (int)a->K;
+    p.Y = a->dY; p.ldy = a->ldy; p.X = a->X; p.ldx = a->ldx;
+    for (int s = 0; s < a->nseg; ++s) {
+        if (a->dW[s] == nullptr || (reinterpret_cast<uintptr_t>(a->dW[s]) & 3u) != 0) return VB_E_BADARG;
+        p.C[s] = a->dW[s];
+    }
+    p.ldc = a->ldw; p.cseg = a->seg_n;
+    p.tiles_k = p.K / HB_BN;
+    p.tiles = (p.N / HB_BM) * p.tiles_k;
+    p.nkt = (p.M + HB_BK - 1) / HB_BK;
+    // units of ~24 or more contraction tiles, a whole number of rounds of the 256 persistent blocks where the sizes allow
+    const long work = (long)p.tiles * p.nkt;
+    const int rounds = (int)((work + 256 * 24 / 2) / (256 * 24)) > 0 ? (int)((work + 256 * 24 / 2) / (256 * 24)) : 1;
+    int splits = (256 * rounds) / p.tiles;
+    if (splits < 1) splits = 1;
+    if (splits > p.nkt) splits = p.nkt;
+    p.kt_per_split = (p.nkt + splits - 1) / splits;
+    p.splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
+    p.units = p.tiles * p.splits;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    const int grid = p.units < 256 ? p.units : 256;
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(grid), dim3(HB_THREADS), HB_LDS, static_cast<hipStream_t>(stream), p);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_cast_f32_bf16(void* stream, int64_t n, const float* x, uint16_t* y) {
+    if (x == nullptr || y == nullptr || n <= 0) return VB_E_BADARG;
+    if (!vb_aligned16(x) || !vb_aligned16(y)) return VB_E_ALIGN;
+    const long n8 = n / 8;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       n8, x, y, (long)n);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_cast_bf16_f32(void* stream, int64_t n, const uint16_t* x, float* y) {
+    if (x == nullptr || y == nullptr || n <= 0) return VB_E_BADARG;
+    if (!vb_aligned16(x) || !vb_aligned16(y)) return VB_E_ALIGN;
+    const long n8 = n / 8;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       n8, x, y, (long)n);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_weight_shadow_bf16(void* stream, int32_t rows, int32_t cols, const float* w, int64_t ldw, uint16_t* w16,
+                                     int64_t ld16, uint16_t* wt16, int64_t ldt) {
+    if (w == nullptr || (w16 == nullptr && wt16 == nullptr) || rows <= 0 || cols <= 0) return VB_E_BADARG;
+    if (rows % 64 != 0 || cols % 64 != 0 || ldw % 4 != 0 || !vb_aligned16(w)) return VB_E_ALIGN;
+    if (w16 != nullptr && (ld16 % 4 != 0 || ld16 < cols || (reinterpret_cast<uintptr_t>(w16) & 7u) != 0)) return VB_E_ALIGN;
+    if (wt16 != nullptr && (ldt % 4 != 0 || ldt < rows || (reinterpret_cast<uintptr_t>(wt16) & 7u) != 0)) return VB_E_ALIGN;
+    hipLaunchKernelGGL(weight_shadow_kernel, dim3(cols / 64, rows / 64), dim3(256), 0, static_cast<hipStream_t>(stream), rows, cols,
+                       w, (long)ldw, w16, (long)ld16, wt16, (long)ldt);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t vb_colsum_bf16_workspace(int32_t cols) { return (int64_t)CS_SLABS * cols; }
+
+extern "C" int vb_colsum_bf16(void* stream, int64_t rows, int32_t cols, const uint16_t* x, int64_t ldx, float* out,
+                              float* workspace) {
+    if (x == nullptr || out == nullptr || workspace == nullptr || rows <= 0 || cols <= 0) return VB_E_BADARG;
+    if (cols % 4 != 0 || ldx % 4 != 0 || ldx < cols || (reinterpret_cast<uintptr_t>(x) & 7u) != 0 || !vb_aligned16(workspace))
+        return VB_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum16_kernel, dim3((cols + 255) / 256, CS_SLABS), dim3(256), 0, st, (long)rows, cols, x, (long)ldx, workspace);
+    VB_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum16_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, cols, workspace, out);
+    VB_LAUNCH_CHECK();
+    return 0;
+}

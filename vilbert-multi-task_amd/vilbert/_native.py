@@ -76,6 +76,35 @@ class LinearMxArgs(ctypes.Structure):
     ]
 
 
+class LinearBf16Args(ctypes.Structure):
+    """vb_linear_bf16_args"""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_int64),
+        ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+        ("bias", _c_f32p),
+        ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64),
+        ("C32", _c_f32p), ("ldc32", ctypes.c_int64),
+        ("residual", ctypes.c_void_p), ("ldr", ctypes.c_int64),
+        ("mul", ctypes.c_void_p), ("ldm", ctypes.c_int64),
+        ("act_grad", ctypes.c_void_p), ("ldg", ctypes.c_int64),
+        ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+        ("act", ctypes.c_int32),
+        ("dropout_p", ctypes.c_float),
+        ("seed", ctypes.c_uint64),
+    ]
+
+
+class WgradBf16Args(ctypes.Structure):
+    """vb_wgrad_bf16_args"""
+    _fields_ = [
+        ("dY", ctypes.c_void_p), ("ldy", ctypes.c_int64),
+        ("X", ctypes.c_void_p), ("ldx", ctypes.c_int64),
+        ("dW", _c_f32p * VB_MAX_SEGMENTS), ("ldw", ctypes.c_int64),
+        ("M", ctypes.c_int64), ("K", ctypes.c_int64),
+        ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32),
+    ]
+
+
 class AttentionMxArgs(ctypes.Structure):
     """vb_attention_mx_args"""
     _fields_ = [
@@ -215,6 +244,16 @@ SIGNATURES = {
     "vb_kl_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _F32, _P, _P, _P, _P, _P]),
     "vb_kl_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _I64, _P]),
     "vb_concap_finish_batch": (ctypes.c_int, [_P, ctypes.POINTER(ConcapBatch)]),
+    "vb_linear_bf16": (ctypes.c_int, [_P, ctypes.POINTER(LinearBf16Args)]),
+    "vb_wgrad_bf16": (ctypes.c_int, [_P, ctypes.POINTER(WgradBf16Args)]),
+    "vb_colsum_bf16_workspace": (_I64, [_I32]),
+    "vb_colsum_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _P]),
+    "vb_weight_shadow_bf16": (ctypes.c_int, [_P, _I32, _I32, _P, _I64, _P, _I64, _P, _I64]),
+    "vb_cast_f32_bf16": (ctypes.c_int, [_P, _I64, _P, _P]),
+    "vb_cast_bf16_f32": (ctypes.c_int, [_P, _I64, _P, _P]),
+    "vb_layernorm_fwd_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _F32, _P, _P, _P]),
+    "vb_layernorm_bwd_bf16_workspace": (_I64, [_I64, _I32]),
+    "vb_layernorm_bwd_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _U64]),
 }
 
 _lib = None
@@ -232,7 +271,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 14:
+        if handle.vb_abi_version() != 15:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") in ("fp8", "mxfp8"):
