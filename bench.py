@@ -245,6 +245,10 @@ def main():
                     "exchange, AdamW - into ONE HIP graph (vilbert/graphed.py) and time the replays")
     ap.add_argument("--global-batch", type=int, default=0, help="GLOBAL batch divided over the ranks (strong scaling; the "
                     "reference's own data-parallel mode, train_concap.py:290-294) instead of a fixed per-GPU batch")
+    ap.add_argument("--label-gather", choices=["auto", "exact"], default="auto",
+                    help="(train) gather of the labelled rows in front of the pre-training heads: auto = fixed capacity fixed by "
+                         "the first step's counts, no host sync per step (overflow checked after every timed region); exact = "
+                         "torch.nonzero per step (one host sync)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the global512 / fwd_b512 legs of the default line")
     ap.add_argument("--deterministic", action="store_true", help="deterministic split-K weight gradients "
                     "(vb_set_deterministic: workspace + ordered reduce instead of atomics; single stream)")
@@ -335,6 +339,9 @@ def main():
             no_decay = [p for n, p in net.named_parameters() if p.requires_grad and any(
                 k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
             from vilbert.optim import AdamW   # native multi-tensor launch, pytorch-transformers 1.0.0 semantics
+            base_net = net.module if hasattr(net, "module") else net
+            if args.label_gather == "auto":
+                base_net.label_capacity = "auto"
             train_state["model"] = net
             train_state["opt"] = AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}],
                                        lr=1e-4, betas=(0.9, 0.98))   # train_concap.py:465-470
@@ -530,6 +537,13 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # fixed-capacity label gather (--label-gather auto): a batch that exceeded the capacity would have dropped rows -
+        # checked here, outside the timed region (raises)
+        m_ = train_state.get("model")
+        if m_ is not None:
+            m_ = m_.module if hasattr(m_, "module") else m_
+            if getattr(m_, "label_capacity", None) is not None:
+                m_.check_label_capacity()
         return dt
 
     elapsed = timed(step, args.warmup, args.steps)
@@ -840,6 +854,13 @@ def main():
                          "flops_per_launch_avg": round(gemm_flops / max(gemm_launches, 1), 0)},
         }
         line["config"]["gemm_mode"] = args.gemm_mode
+        if args.mode == "train":
+            bm = train_state.get("model")
+            bm = bm.module if hasattr(bm, "module") else bm
+            cap = getattr(bm, "_auto_capacity", None)
+            line["config"]["label_gather"] = "exact (torch.nonzero, one host sync per step)" if args.label_gather == "exact" or cap is None \
+                else "fixed capacity %.3f of the positions (1.2 x the first step's labelled fraction + 0.01), no host sync per step; " \
+                     "overflow checked after every timed region" % cap
         # the STATE, not the flag: ordered split-K is the default (VB_DETERMINISTIC=0 switches to atomics); fallbacks =
         # split launches that wanted the ordered reduce and ran with atomics (no free workspace slice)
         line["config"]["deterministic_wgrad"] = bool(_native._DET["wanted"]) and _native.deterministic_workspace(device) is not None

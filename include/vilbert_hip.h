@@ -557,7 +557,7 @@ int vb_concap_finish_batch(void* stream, const vb_concap_batch* a);
  * vb_linear_bf16:  C[M][N] = epilogue(A[M][K] W[N][K]^T), both operands contraction-contiguous. Forward: W = the shadow of
  *   nn.Linear.weight (stacked segments are stacked in the shadow). Input gradient: A = dY [M][N'], W = the TRANSPOSED shadow
  *   [K'][N'] -> dX [M][K'] (the same kernel). K % 64 == 0, N % 128 == 0; A / W 16-byte aligned, lda / ldw % 8 == 0.
- *   v = acc + bias[n] (bias fp32 or NULL), then exactly one of:
+ *   v = acc + bias[n] (fp32, in up to VB_MAX_SEGMENTS equal column segments; NULL = none), then exactly one of:
  *     act = GELU: gelu(v) (vilbert.py:111-117), and gelu'(v) to act_grad if given (bf16 [M][N]);  act = RELU: max(v, 0);
  *     residual (bf16 [M][N]):  dropout(v, dropout_p, seed) + residual   (mask element index = m * N + n, rng.h - the
  *         index vb_layernorm_bwd_bf16 regenerates it from; dropout only together with a residual);
@@ -565,7 +565,8 @@ int vb_concap_finish_batch(void* stream, const vb_concap_batch* a);
  *   written as bf16 to C (ldc % 2 == 0) or as fp32 to C32 (plain / residual / RELU only). Rows >= M are never stored.
  * vb_wgrad_bf16:   dW_s[seg_n][K] += dY[:, s seg_n : (s + 1) seg_n]^T X   for the nseg stacked segments of dY [M][nseg seg_n]
  *   (contraction over the M rows: row-major tiles in LDS, fragments by the transposing LDS read ds_read_b64_tr_b16), fp32
- *   atomics into dW (the gradient-arena slices: zero-filled once per backward pass, or holding an earlier contribution).
+ *   atomics into dW (the gradient-arena slices: zero-filled once per backward pass, or holding an earlier contribution);
+ *   dbias_s[seg_n] += the column sums of the segment's dY (the bias gradient, from the fragments the kernel holds anyway).
  *   seg_n % 256 == 0, K % 128 == 0, any M; dY / X 16-byte aligned, ldy / ldx % 8 == 0.
  * vb_colsum_bf16:  out[c] += sum_m x[m][c] (the bias gradient of the same dY), two deterministic stages through `workspace`
  *   (vb_colsum_bf16_workspace(cols) floats). cols % 4 == 0.
@@ -579,12 +580,51 @@ int vb_concap_finish_batch(void* stream, const vb_concap_batch* a);
  *   vb_layernorm_bwd_bf16_workspace(rows, n_cols) floats); dx_dropped (optional, with 0 < dropout_p < 1): dx under the
  *   dropout mask (seed, row * n_cols + col) of the dense layer in front, written in the same pass. n_cols % 4 == 0, <= 1024.
  * ------------------------------------------------------------------------------------------ */
+/* Attention of the bf16 training path: exactly vb_attention_fwd / vb_attention_bwd (same kernels, csrc/attention.hip
+ * compiled with -DVB_ATTN_BF16; same argument meaning, same limits) with Q, K, V, O and dO, dQ, dK, dV as bf16 bit patterns
+ * (row strides in ELEMENTS % 4 == 0, pointers 8-byte aligned); mask_add, probs, lse and dvec stay fp32; the operands are
+ * widened to fp32 on their way into registers / LDS, products on the exact-fp32 MFMA, fp32 softmax. */
+typedef struct {
+    int32_t batch, heads, head_dim, n_q, n_k;
+    int32_t q_batch, kv_batch;
+    const uint16_t* Q;
+    int64_t ldq;
+    const uint16_t* K;
+    int64_t ldk;
+    const uint16_t* V;
+    int64_t ldv;
+    const float* mask_add;
+    uint16_t* O;
+    int64_t ldo;
+    float* probs;
+    float* lse;
+    float scale;
+    float dropout_p;
+    uint64_t seed;
+} vb_attention_bf16_args;
+
+typedef struct {
+    const uint16_t* dO;
+    int64_t lddo;
+    uint16_t* dQ;
+    int64_t lddq;
+    uint16_t* dK;
+    int64_t lddk;
+    uint16_t* dV;
+    int64_t lddv;
+    float* dvec;
+} vb_attention_bf16_grads;
+
+int vb_attention_fwd_bf16(void* stream, const vb_attention_bf16_args* a);
+int vb_attention_bwd_bf16(void* stream, const vb_attention_bf16_args* a, const vb_attention_bf16_grads* gr);
+
 typedef struct {
     const uint16_t* A;
     int64_t lda;
     const uint16_t* W;
     int64_t ldw;
-    const float* bias;          /* [N] or NULL */
+    const float* bias[VB_MAX_SEGMENTS]; /* bias of output columns [s N / bias_segments, (s + 1) N / bias_segments), or NULL */
+    int32_t bias_segments;      /* 0 or 1: one bias of N values; stacked weights pass their nn.Linear biases unpacked */
     uint16_t* C;                /* bf16 out, or NULL */
     int64_t ldc;
     float* C32;                 /* fp32 out, or NULL (exactly one of C / C32) */
@@ -610,6 +650,7 @@ typedef struct {
     int64_t ldx;
     float* dW[VB_MAX_SEGMENTS];
     int64_t ldw;
+    float* dbias[VB_MAX_SEGMENTS];  /* [seg_n] each, ADDED into; NULL = no bias gradient for that segment */
     int64_t M, K;
     int32_t nseg, seg_n;
 } vb_wgrad_bf16_args;
@@ -620,6 +661,18 @@ int64_t vb_colsum_bf16_workspace(int32_t cols);
 int vb_colsum_bf16(void* stream, int64_t rows, int32_t cols, const uint16_t* x, int64_t ldx, float* out, float* workspace);
 int vb_weight_shadow_bf16(void* stream, int32_t rows, int32_t cols, const float* w, int64_t ldw, uint16_t* w16, int64_t ld16,
                           uint16_t* wt16, int64_t ldt);
+/* every registered weight in ONE launch (after an optimizer step): `table` = n_segs DEVICE records, one per weight segment -
+ * w fp32 [rows][cols] contiguous, w16 / wt16 as vb_weight_shadow_bf16 (both required), tile0 = the number of 64 x 64 tiles of
+ * all earlier records (ascending); total_tiles = the sum over all records of (rows / 64) (cols / 64). */
+typedef struct {
+    const float* w;
+    uint16_t* w16;
+    uint16_t* wt16;
+    int32_t rows, cols;
+    int64_t ld16, ldt;
+    int64_t tile0;
+} vb_shadow_seg;
+int vb_weight_shadow_multi(void* stream, int32_t n_segs, const vb_shadow_seg* table, int64_t total_tiles);
 int vb_cast_f32_bf16(void* stream, int64_t n, const float* x, uint16_t* y);
 int vb_cast_bf16_f32(void* stream, int64_t n, const uint16_t* x, float* y);
 int vb_layernorm_fwd_bf16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* x, const float* gamma, const float* beta,

@@ -177,7 +177,7 @@ def run_concap(work):
     observed.update(model_class_file=os.path.relpath(sys.modules[ns["BertForMultiModalPreTraining"].__module__].__file__, ROOT),
                     adamw_file=os.path.relpath(sys.modules[ns["AdamW"].__module__].__file__, ROOT),
                     loader_file=sys.modules["vilbert.datasets"].__file__,
-                    tblogger_file=ns["utils"].tbLogger.__module__, files_written=ckpts)
+                    tblogger_file=ns["utils"].tbLogger.__init__.__code__.co_filename, files_written=ckpts)
     return observed
 
 

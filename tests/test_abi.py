@@ -36,7 +36,7 @@ def test_header_declares_the_expected_entry_points():
 EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_quantize_rows_mx", "vb_linear_fwd_mx", "vb_layernorm_fwd_mx", "vb_attention_fwd_mx", "vb_layernorm_fwd_mx16", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd",
                # round 5: the bf16 training path (csrc/gemm_bf16.hip, rowops16.hip)
-               "vb_linear_bf16", "vb_wgrad_bf16", "vb_colsum_bf16_workspace", "vb_colsum_bf16", "vb_weight_shadow_bf16",
+               "vb_attention_fwd_bf16", "vb_attention_bwd_bf16", "vb_linear_bf16", "vb_wgrad_bf16", "vb_colsum_bf16_workspace", "vb_colsum_bf16", "vb_weight_shadow_bf16", "vb_weight_shadow_multi",
                "vb_cast_f32_bf16", "vb_cast_bf16_f32", "vb_layernorm_fwd_bf16", "vb_layernorm_bwd_bf16_workspace",
                "vb_layernorm_bwd_bf16"]
 

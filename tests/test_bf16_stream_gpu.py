@@ -1,0 +1,372 @@
+"""The bf16 TRAINING path (round 5; csrc/gemm_bf16.hip, rowops16.hip, attention.hip -DVB_ATTN_BF16; vilbert/ops16.py):
+bfloat16 activations / saved tensors / activation gradients, fp32 master weights, fp32 gradient accumulation - the mode
+that replaces the reference's `model.half()` + apex FP16_Optimizer (/root/reference/train_concap.py:443-461,504-505).
+
+Bars (this mode's own - it is outside the fp32 1e-4 bar by construction and never the default):
+  * every kernel against float64 arithmetic on the SAME bf16 operand values: the only errors allowed are the fp32
+    accumulation (<= 3e-6 sum|a b|) and ONE bf16 rounding of the result (|want| / 256);
+  * the attention kernels are the fp32 kernels with bf16 loads / stores: their outputs must equal the fp32 kernels' outputs
+    on the same values rounded to bf16, bit for bit;
+  * dropout masks are the fp32 path's (same (seed, element index) function): checked against vb_dropout;
+  * model level: forward drift against the fp32 oracle bounded and printed; every parameter gradient against the exact-fp32
+    mode (relative L2 per tensor, median / 90th percentile / worst printed and bounded); 200 AdamW steps track the fp32 CPU
+    oracle's loss curve.
+"""
+import pytest
+import torch
+
+import helpers
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16 = torch.bfloat16
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _close16(got, want64, mag64, what):
+    """got (bf16 or fp32 tensor) vs float64 `want`: fp32 accumulation + one bf16 rounding (fp32 outputs: accumulation only)."""
+    g = got.detach().cpu().double()
+    assert g.shape == want64.shape and torch.isfinite(g).all(), what
+    tol = 3e-6 * mag64 + 1e-5 + (want64.abs() / 256 if got.dtype == BF16 else 0.0)
+    err = (g - want64).abs()
+    assert (err <= tol).all(), "%s: worst err / tol %.3f" % (what, float((err / tol).max()))
+
+
+@pytest.mark.parametrize("M,nseg,seg_n,K", [(300, 1, 768, 768), (77, 3, 256, 128), (640, 1, 1024, 2048), (1, 1, 256, 128),
+                                            (2368, 3, 1024, 1024)])
+def test_linear16_forward_dgrad_wgrad_match_float64(M, nseg, seg_n, K):
+    from vilbert import ops, ops16
+    N_ = nseg * seg_n
+    x = _rand(M, K, seed=1).to(BF16)
+    ws = [_rand(seg_n, K, seed=10 + i, scale=0.05) for i in range(nseg)]
+    bs = [_rand(seg_n, seed=20 + i) for i in range(nseg)]
+    r = _rand(M, N_, seed=3).to(BF16)
+    wd, bd = [w.to(DEV) for w in ws], [b.to(DEV) for b in bs]
+    w16 = torch.cat(ws).to(BF16).double()               # what the shadow holds
+    pre = x.double() @ w16.t() + torch.cat(bs).double()
+    mag = x.double().abs() @ w16.abs().t() + 1.0
+    # forward: plain, GELU + derivative, residual, fp32 output
+    y, _ = ops16.linear_fwd(x.to(DEV), wd, bd)
+    _close16(y, pre, mag, "forward")
+    y, d = ops16.linear_fwd(x.to(DEV), wd, bd, "gelu", want_act_grad=True)
+    _close16(y, torch.nn.functional.gelu(pre), mag, "forward + GELU")
+    phi = 0.5 * (1 + torch.erf(pre / 2 ** 0.5))
+    _close16(d, phi + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5, mag, "GELU derivative")
+    y, _ = ops16.linear_fwd(x.to(DEV), wd, bd, None, r.to(DEV))
+    _close16(y, pre + r.double(), mag, "forward + residual")
+    y, _ = ops16.linear_fwd(x.to(DEV), wd, bd, out_f32=True)
+    assert y.dtype == torch.float32
+    _close16(y, pre, mag, "forward, fp32 out")
+    # dropout + residual: the mask is the fp32 path's (seed, row * N + col)
+    seed, p = 0x5EED5EED5EED, 0.25
+    y, _ = ops16.linear_fwd(x.to(DEV), wd, bd, None, r.to(DEV), drop_p=p, seed=seed)
+    keep = ops.dropout(torch.ones(M, N_, device=DEV), p, seed).cpu() != 0
+    _close16(y, torch.where(keep, pre / (1 - p), torch.zeros_like(pre)) + r.double(), mag, "forward + dropout + residual")
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.05 or M * N_ < 4096
+    # input gradient: plain, + residual gradient, x saved derivative
+    dy = _rand(M, N_, seed=4).to(BF16)
+    rk, mk = _rand(M, K, seed=5).to(BF16), _rand(M, K, seed=6).to(BF16)
+    want = dy.double() @ w16
+    magd = dy.double().abs() @ w16.abs() + 1.0
+    _close16(ops16.linear_bwd_input(dy.to(DEV), wd, bd, K), want, magd, "dgrad")
+    _close16(ops16.linear_bwd_input(dy.to(DEV), wd, bd, K, residual=rk.to(DEV)), want + rk.double(), magd, "dgrad + residual")
+    got = ops16.linear_bwd_input(dy.to(DEV), wd, bd, K, mul=mk.to(DEV))
+    _close16(got, want * mk.double(), magd * mk.double().abs() + 1.0, "dgrad x multiplier")
+    # weight / bias gradient: ADDED into the targets
+    init_w = [_rand(seg_n, K, seed=30 + i) for i in range(nseg)]
+    init_b = [_rand(seg_n, seed=40 + i) for i in range(nseg)]
+    tw, tb = [t.to(DEV) for t in init_w], [t.to(DEV) for t in init_b]
+    dws, dbs = ops16.linear_bwd_weight(dy.to(DEV), x.to(DEV), nseg, seg_n, [True] * nseg, dw_out=tw, db_out=tb)
+    for s in range(nseg):
+        seg = dy[:, s * seg_n:(s + 1) * seg_n].double()
+        assert dws[s] is tw[s] and dbs[s] is tb[s]
+        _close16(dws[s], init_w[s].double() + seg.t() @ x.double(), seg.abs().t() @ x.double().abs() + 1.0, "wgrad %d" % s)
+        _close16(dbs[s], init_b[s].double() + seg.sum(0), seg.abs().sum(0) + 1.0, "bias grad %d" % s)
+    dws, dbs = ops16.linear_bwd_weight(dy.to(DEV), x.to(DEV), nseg, seg_n, [s == 0 for s in range(nseg)])
+    assert dbs[0] is not None and all(b is None for b in dbs[1:])
+    _close16(dws[-1], dy[:, -seg_n:].double().t() @ x.double(), dy[:, -seg_n:].double().abs().t() @ x.double().abs() + 1.0,
+             "wgrad into a fresh buffer")
+
+
+def test_weight_shadows_follow_the_parameters():
+    from vilbert import _native, ops16
+    w = torch.nn.Parameter(_rand(256, 128, seed=1).to(DEV))
+    b = torch.nn.Parameter(_rand(256, seed=2).to(DEV))
+    w2 = torch.nn.Parameter(_rand(256, 128, seed=3).to(DEV))
+    w16, wt16 = ops16.shadows([w])
+    s16, st16 = ops16.shadows([w, w2])                            # another stacking of the same first weight: its own entry
+    assert torch.equal(w16, w.detach().to(BF16)) and torch.equal(wt16, w.detach().to(BF16).t())
+    assert torch.equal(s16, torch.cat([w, w2]).detach().to(BF16)) and torch.equal(st16, torch.cat([w, w2]).detach().to(BF16).t())
+    w16, wt16 = ops16.shadows([w])
+    assert ops16.shadows([w])[0] is w16                           # cached
+    with torch.no_grad():
+        w.add_(1.0)                                               # torch's version counter
+    again = ops16.shadows([w])
+    assert again[0] is w16 and torch.equal(w16, w.detach().to(BF16)), "refreshed in place"
+    other = ops16.shadows([w2])                                   # (a second registered weight: the one-launch refresh covers both)
+    with torch.no_grad():
+        w.data.view(-1)[:4] = 7.0                                 # behind torch's back (what the native optimizer does) ...
+        w2.data.view(-1)[:4] = -3.0
+    _native.weights_changed()                                     # ... announced through the epoch
+    assert torch.equal(ops16.shadows([w])[1], w.detach().to(BF16).t())
+    assert torch.equal(other[0], w2.detach().to(BF16)) and torch.equal(s16, torch.cat([w, w2]).detach().to(BF16)), \
+        "the one-launch refresh covers every registered weight"
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 768), (130, 1024), (5, 256)])
+def test_layernorm16_forward_backward(rows, cols):
+    from vilbert import ops, ops16
+    x = (_rand(rows, cols, seed=rows) * 2 + 0.3).to(BF16)
+    dy = _rand(rows, cols, seed=rows + 1).to(BF16)
+    g, b = 1 + 0.1 * _rand(cols, seed=3), 0.1 * _rand(cols, seed=4)
+    y, mean, rstd = ops16.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), 1e-12, want_stats=True)
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    var = ((xd - mu) ** 2).mean(1, keepdim=True)
+    xh = (xd - mu) / torch.sqrt(var + 1e-12)
+    _close16(y, g.double() * xh + b.double(), torch.ones(rows, cols, dtype=torch.float64) * 4, "LayerNorm forward")
+    assert (mean.cpu().double() - mu[:, 0]).abs().max() < 1e-5 and (rstd.cpu().double() * torch.sqrt(var[:, 0] + 1e-12) - 1).abs().max() < 1e-5
+    gd = dy.double() * g.double()
+    want = (gd - gd.mean(1, keepdim=True) - xh * (gd * xh).mean(1, keepdim=True)) / torch.sqrt(var + 1e-12)
+    seed, p = 1234567, 0.1
+    dx, dgam, dbet, dxd = ops16.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), drop=(p, seed))
+    scale = torch.ones(rows, cols, dtype=torch.float64) * float(want.abs().max()) * 4
+    _close16(dx, want, scale, "LayerNorm backward dx")
+    _close16(dgam, (dy.double() * xh).sum(0), (dy.double() * xh).abs().sum(0) + 1, "dgamma")
+    _close16(dbet, dy.double().sum(0), dy.double().abs().sum(0) + 1, "dbeta")
+    keep = ops.dropout(torch.ones(rows, cols, device=DEV), p, seed).cpu() != 0
+    _close16(dxd, torch.where(keep, want / (1 - p), torch.zeros_like(want)), scale, "dx under the dropout mask")
+    dx2 = ops16.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV))[0]
+    assert torch.equal(dx2, dx)
+
+
+@pytest.mark.parametrize("B,heads,d,Sq,Sk,drop", [(3, 12, 64, 36, 36, 0.0), (2, 8, 128, 37, 37, 0.1), (2, 8, 128, 36, 37, 0.0),
+                                                   (2, 8, 128, 24, 101, 0.1), (1, 4, 64, 101, 24, 0.0), (2, 2, 32, 9, 7, 0.0)])
+def test_attention16_is_the_fp32_kernel_with_bf16_loads_and_stores(B, heads, d, Sq, Sk, drop):
+    from vilbert import ops, ops16
+    H = heads * d
+    qkv_q = (_rand(B, Sq, 3 * H, seed=Sq) * 0.7).to(BF16).to(DEV)
+    qkv_k = (_rand(B, Sk, 3 * H, seed=Sk + 100) * 0.7).to(BF16).to(DEV)
+    keep = (torch.rand(B, Sk, generator=torch.Generator().manual_seed(7)) > 0.2).float()
+    keep[:, 0] = 1
+    mask = ((1.0 - keep) * -10000.0).to(DEV)
+    d_out = _rand(B, Sq, H, seed=9).to(BF16).to(DEV)
+    seed = 424242
+    q16, k16, v16 = qkv_q[..., :H], qkv_k[..., H:2 * H], qkv_k[..., 2 * H:]
+    out16, lse16 = ops16.attention_fwd(q16, k16, v16, mask, heads, True, drop, seed)
+    f_q, f_k = qkv_q.float(), qkv_k.float()
+    q32, k32, v32 = f_q[..., :H], f_k[..., H:2 * H], f_k[..., 2 * H:]
+    out32, _, lse32 = ops.attention_fwd(q32, k32, v32, mask, heads, False, True, drop, seed)
+    assert out16.dtype == BF16 and torch.equal(lse16, lse32)
+    assert torch.equal(out16, out32.to(BF16)), "%d elements differ" % int((out16 != out32.to(BF16)).sum())
+    dq16 = torch.empty(B, Sq, 3 * H, dtype=BF16, device=DEV)
+    dk16 = torch.empty(B, Sk, 3 * H, dtype=BF16, device=DEV)
+    ops16.attention_bwd(d_out, q16, k16, v16, mask, heads, lse16, dq16[..., :H], dk16[..., H:2 * H], dk16[..., 2 * H:], drop, seed)
+    dq32 = torch.empty(B, Sq, 3 * H, device=DEV)
+    dk32 = torch.empty(B, Sk, 3 * H, device=DEV)
+    ops.attention_bwd(d_out.float(), q32, k32, v32, mask, heads, lse32, dq32[..., :H], dk32[..., H:2 * H], dk32[..., 2 * H:], drop, seed)
+    for got, want, nm in ((dq16[..., :H], dq32[..., :H], "dq"), (dk16[..., H:2 * H], dk32[..., H:2 * H], "dk"),
+                          (dk16[..., 2 * H:], dk32[..., 2 * H:], "dv")):
+        assert torch.equal(got, want.to(BF16)), "%s: %d elements differ" % (nm, int((got != want.to(BF16)).sum()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# model level
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def bf16_mode():
+    from vilbert import _native
+    prev = _native.set_gemm_mode("bf16")
+    yield
+    _native.set_gemm_mode(prev)
+
+
+NAMES = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+         "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
+
+
+def test_model_runs_its_encoder_on_the_bf16_kernels(bf16_mode, monkeypatch):
+    """bert_base_2layer_2conect, the train_concap shapes (T = 36, R = 37): which launcher serves which linear, what dtype the
+    hidden states have, that forward + backward run without a single fp32 encoder GEMM, and that an AdamW step refreshes the
+    shadows."""
+    import vilbert.vilbert as V
+    from vilbert import _native, ops, ops16
+    from vilbert.optim import AdamW
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    assert _native.bf16_stream()
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    sd = synth.make_state_dict(cfg, "pretraining")
+    x = synth.make_inputs(cfg, 4, 36, 37, with_labels=True)
+    args = [x[n].to(DEV) for n in NAMES]
+    m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    calls = {"fwd16": [], "fwd32": [], "dgrad16": 0, "dgrad32": 0, "wgrad16": 0, "wgrad32": 0, "attn16": 0, "attn32": 0, "ln16": 0}
+    real = {n: getattr(ops16, n) for n in ("linear_fwd", "linear_bwd_input", "linear_bwd_weight", "attention_fwd", "layernorm_fwd")}
+    real32 = {n: getattr(ops, n) for n in ("linear_fwd", "linear_bwd_input", "linear_bwd_weight", "attention_fwd")}
+
+    def count(key, fn, shape_of=None):
+        def w(*a, **k):
+            if shape_of is not None:
+                calls[key].append(shape_of(*a, **k))
+            else:
+                calls[key] += 1
+            return fn(*a, **k)
+        return w
+    shp = lambda x_, ws, *a, **k: (len(ws) * ws[0].shape[0], ws[0].shape[1])
+    monkeypatch.setattr(ops16, "linear_fwd", count("fwd16", real["linear_fwd"], shp))
+    monkeypatch.setattr(ops16, "linear_bwd_input", count("dgrad16", real["linear_bwd_input"]))
+    monkeypatch.setattr(ops16, "linear_bwd_weight", count("wgrad16", real["linear_bwd_weight"]))
+    monkeypatch.setattr(ops16, "attention_fwd", count("attn16", real["attention_fwd"]))
+    monkeypatch.setattr(ops16, "layernorm_fwd", count("ln16", real["layernorm_fwd"]))
+    monkeypatch.setattr(ops, "linear_fwd", count("fwd32", real32["linear_fwd"], lambda x_, ws, *a, **k: (len(ws) * ws[0].shape[0], ws[0].shape[1])))
+    monkeypatch.setattr(ops, "linear_bwd_input", count("dgrad32", real32["linear_bwd_input"]))
+    monkeypatch.setattr(ops, "linear_bwd_weight", count("wgrad32", real32["linear_bwd_weight"]))
+    monkeypatch.setattr(ops, "attention_fwd", count("attn32", real32["attention_fwd"]))
+    seen = []
+    hook = m.bert.encoder.layer[0].register_forward_hook(lambda mod, i, o: seen.append((i[0].dtype, o[0].dtype)))
+    opt = AdamW(m.parameters(), lr=1e-4)
+    loss0 = sum(l.mean() for l in m(*args))
+    loss0.backward()
+    hook.remove()
+    assert seen == [(BF16, BF16)]
+    # 2 text + 2 image layers (4 linears each) + 2 connection layers (2 + 2 + 4) + the region-feature projection
+    assert len(calls["fwd16"]) >= 12 * 2 + 5 and calls["attn16"] >= 6 and calls["attn32"] == 0 and calls["ln16"] >= 12
+    # what stays on the fp32-tensor kernels: the two poolers, the heads' transforms / decoders / classifiers - never a 2304- /
+    # 3072-wide projection or an FFN
+    assert len(calls["fwd32"]) <= 10 and all(n not in (2304, 3072) and k != 3072 for n, k in calls["fwd32"]), calls["fwd32"]
+    assert calls["dgrad16"] >= 20 and calls["wgrad16"] >= 20
+    # the pre-training heads (transform 768 -> 768, 1024 -> 1024) legitimately run on the fp32-tensor kernels: not more than those
+    assert calls["dgrad32"] <= 8 and calls["wgrad32"] <= 10, calls
+    for n, p_ in m.named_parameters():
+        assert p_.grad is None or (p_.grad.dtype == torch.float32 and torch.isfinite(p_.grad).all()), n
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    loss1 = sum(l.mean() for l in m(*args))
+    q = m.bert.encoder.layer[0].attention.self
+    w16 = ops16.shadows([q.query.weight, q.key.weight, q.value.weight])[0]
+    assert torch.equal(w16[:768], q.query.weight.detach().to(BF16)), "the shadow must follow the optimizer step"
+    assert torch.isfinite(loss1) and abs(loss1.item() - loss0.item()) > 0
+
+
+def test_bf16_stream_forward_drift_and_gradient_error_are_reported(bf16_mode):
+    """The timed model family at a size the oracle finishes in seconds: bert_base_6layer_6conect, B = 4, T = 36, R = 37, dropout
+    off. Losses against the fp32 CPU oracle, every parameter gradient against oracle autograd: relative L2 per tensor."""
+    import vilbert.vilbert as V
+    from oracle import vilbert_oracle as vo
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    cfg = synth.load_config("bert_base_6layer_6conect.json")
+    sd = synth.make_state_dict(cfg, "pretraining")
+    x = synth.make_inputs(cfg, 4, 36, 37, with_labels=True)
+    args = [x[n] for n in NAMES]
+    m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    orig, V._drop_p = V._drop_p, (lambda mod: 0.0)
+    try:
+        losses = m(*helpers.to_device(args, DEV))
+        sum(l.sum() for l in losses).backward()
+    finally:
+        V._drop_p = orig
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.predictions.decoder.weight"}
+    leaves["cls.predictions.decoder.weight"] = leaves["bert.embeddings.word_embeddings.weight"]
+    want = vo.pretraining_forward(leaves, cfg, *args)
+    sum(l.sum() for l in want).backward()
+    for g, w, n in zip(losses, want, ("masked_lm_loss", "masked_img_loss", "next_sentence_loss")):
+        rel = abs(g.item() - w.item()) / abs(w.item())
+        print("bf16 stream, 6L/6C B=4: %s %.5f vs fp32 oracle %.5f (relative %.2e)" % (n, g.item(), w.item(), rel))
+        assert rel <= 2e-2, (n, g.item(), w.item())
+    ref = {n: leaves[n].grad.double() for n, p in m.named_parameters() if leaves[n].grad is not None}
+    got = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters() if p.grad is not None}
+    assert set(ref) == set(got)
+    typical = sorted(g.norm().item() for g in ref.values())[len(ref) // 2]
+    rel = sorted((got[n] - g).norm().item() / max(g.norm().item(), 1e-3 * typical) for n, g in ref.items())
+    median, p90, worst = rel[len(rel) // 2], rel[len(rel) * 9 // 10], rel[-1]
+    print("bf16 stream, 6L/6C B=4: gradient relative L2 error vs fp32 oracle autograd - median %.3e, 90th percentile %.3e, worst "
+          "%.3e over %d tensors" % (median, p90, worst, len(rel)))
+    assert median <= 0.05 and p90 <= 0.15 and worst <= 0.6, (median, p90, worst)
+    assert median > 1e-6
+
+
+def test_two_hundred_bf16_steps_track_the_fp32_oracle_loss_curve(bf16_mode):
+    """tests/test_loss_curve_gpu.py's experiment in the bf16 mode, on a small two-stream model whose widths the bf16 kernels
+    serve (256-wide streams, 64 / 128-wide heads): 200 AdamW steps on 8 fixed batches, dropout off, against the fp32 CPU
+    oracle (autograd + oracle/adamw_oracle.py). bf16 rounding noise feeds back through 200 steps: window means within 5 %."""
+    import vilbert.vilbert as V
+    from oracle import adamw_oracle as ao
+    from oracle import vilbert_oracle as vo
+    from vilbert import ops16
+    from vilbert.optim import AdamW
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    STEPS, NB, LR = 200, 8, 5e-4
+    cfg = synth.tiny_config(hidden_size=256, num_attention_heads=4, intermediate_size=512, v_feature_size=256, v_hidden_size=256,
+                            v_num_attention_heads=2, v_intermediate_size=256, bi_hidden_size=256, bi_num_attention_heads=2,
+                            vocab_size=211)
+    sd = synth.make_state_dict(cfg, "pretraining", seed=5)
+    batches = [[synth.make_inputs(cfg, 8, 9, 8, seed=50 + i, with_labels=True)[n] for n in NAMES] for i in range(NB)]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k != "cls.predictions.decoder.weight"}
+    leaves["cls.predictions.decoder.weight"] = leaves["bert.embeddings.word_embeddings.weight"]
+    params = {id(v): v for v in leaves.values()}.values()
+    state = {id(v): (torch.zeros_like(v), torch.zeros_like(v)) for v in params}
+    oracle = []
+    for step in range(1, STEPS + 1):
+        for v in params:
+            v.grad = None
+        loss = sum(l.mean() for l in vo.pretraining_forward(leaves, cfg, *batches[(step - 1) % NB]))
+        loss.backward()
+        oracle.append(loss.item())
+        with torch.no_grad():
+            for v in params:
+                if v.grad is not None:
+                    m_, s_ = state[id(v)]
+                    ao.adamw_step(v, v.grad, m_, s_, step, LR, (0.9, 0.999), 1e-6, 0.0, True)
+    dev_batches = [helpers.to_device(b, DEV) for b in batches]
+    used = {"n": 0}
+    real = ops16.linear_fwd
+
+    def spy(*a, **k):
+        used["n"] += 1
+        return real(*a, **k)
+    orig, V._drop_p = V._drop_p, (lambda mod: 0.0)
+    ops16.linear_fwd = spy
+    try:
+        net = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+        net.load_state_dict(sd)
+        net = net.to(DEV).train()
+        opt = AdamW(net.parameters(), lr=LR, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0)
+        curve = []
+        for step in range(STEPS):
+            opt.zero_grad(set_to_none=True)
+            loss = sum(l.mean() for l in net(*dev_batches[step % NB]))
+            loss.backward()
+            opt.step()
+            curve.append(loss.item())
+    finally:
+        V._drop_p = orig
+        ops16.linear_fwd = real
+    assert used["n"] >= STEPS * 20, "the bf16 kernels must have served this model (%d launches)" % used["n"]
+    win = lambda xs, lo: sum(xs[lo:lo + 2 * NB]) / (2 * NB)
+    first, last = win(oracle, 0), win(oracle, STEPS - 2 * NB)
+    assert last < 0.7 * first
+    worst, table = 0.0, []
+    for lo in range(0, STEPS - 2 * NB + 1, 2 * NB):
+        a, b = win(curve, lo), win(oracle, lo)
+        worst = max(worst, abs(a - b) / b)
+        table.append("%d-%d: %.3f / %.3f" % (lo, lo + 2 * NB, a, b))
+        if lo < 6 * NB:
+            assert abs(a - b) <= 0.03 * b, "steps %d-%d: bf16 %.4f vs fp32 oracle %.4f" % (lo, lo + 2 * NB, a, b)
+    area, area_ref = sum(curve), sum(oracle)
+    print("bf16 stream: 200-step loss curve, window means bf16 / fp32 oracle: " + "; ".join(table))
+    print("bf16 stream: %.4f -> %.4f (fp32 oracle %.4f -> %.4f), worst window deviation %.1f %%, area under the curve %.2f vs %.2f"
+          % (win(curve, 0), win(curve, STEPS - 3 * NB), first, last, 100 * worst, area, area_ref))
+    # Same start (bf16 rounding only: the first three windows within 3 %), same learning (area under the curve within 5 %, the
+    # final level within 25 %). In between the two runs are different noise realisations of a small memorisation problem -
+    # bf16 perturbs every step by ~1e-2 relative and the weight-gradient atomics add run-to-run variation: measured worst
+    # window deviations 12 - 14 % around steps 48 - 80, where the loss falls fastest; bound 30 %.
+    assert worst <= 0.30, worst
+    assert abs(area - area_ref) <= 0.05 * area_ref, (area, area_ref)
+    assert win(curve, STEPS - 3 * NB) <= 1.25 * win(oracle, STEPS - 3 * NB) + 0.02 and win(curve, STEPS - 3 * NB) < 0.1 * win(curve, 0)

@@ -3,8 +3,9 @@ bf16 planes per operand) against the same fp64 references as the default exact-f
 against the reference's golden vectors in bf16x6 mode (tolerance unchanged: fp32 1e-4), and the reduced-precision
 "bf16" mode (operands rounded to bf16, one product, fp32 accumulate) under ITS OWN stated tolerance: per GEMM
 |err| <= 2^-7 sqrt(K) max|a| max|b| (two operands rounded at 2^-9 relative each, errors adding in quadrature over K);
-at model level the measured output error against the real reference's golden vectors is asserted <= 3e-2 relative
-to each output's largest magnitude - it does NOT meet the 1e-4 bar and is never the default."""
+at model level the measured output error against the real reference's golden vectors is asserted <= 5e-2 relative
+to each output's largest magnitude (round 5: "bf16" also keeps the encoder's hidden states in bfloat16 - vilbert/ops16.py;
+measured 2.9e-2 on 2L/2C, 1.9e-2 on 6L/6C) - it does NOT meet the 1e-4 bar and is never the default."""
 import pytest
 import torch
 
@@ -92,7 +93,7 @@ def test_bf16x6_model_matches_reference_golden(mode, case):
 @pytest.mark.parametrize("case", ["base_2l2c_b8", "base_6l6c_b2"])
 def test_bf16_mode_model_error_is_reported_under_its_own_tolerance(mode, case):
     """Reduced-precision mode against the REAL reference's outputs: it misses the 1e-4 bar (by design) and is bounded
-    by 3e-2 of each output's largest magnitude; the measured worst ratio is printed for DESIGN.md."""
+    by 5e-2 of each output's largest magnitude; the measured worst ratio is printed for DESIGN.md."""
     from vilbert.vilbert import BertConfig, VILBertForVLTasks
     cfg, sd, x = cases.case_inputs(case)
     m = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
@@ -109,7 +110,7 @@ def test_bf16_mode_model_error_is_reported_under_its_own_tolerance(mode, case):
         want = torch.as_tensor(gold[n]).double()
         rel = ((got - want).abs().max() / want.abs().max()).item()
         worst = max(worst, rel)
-        assert rel <= 3e-2, "%s/%s: bf16-mode error %.3e of the output range" % (case, n, rel)
+        assert rel <= 5e-2, "%s/%s: bf16-mode error %.3e of the output range" % (case, n, rel)
     print("bf16 mode, %s: worst output error %.2e of the output range (fp32 mode: < 1e-4)" % (case, worst))
     assert worst > 1e-5       # it really is a different arithmetic
 

@@ -44,7 +44,7 @@ def test_train_concap_main_runs_unmodified(tmp_path):
     assert got["model_class_file"] == "vilbert-multi-task_amd/vilbert/vilbert.py"          # OUR model class ...
     assert got["adamw_file"] == "vilbert-multi-task_amd/vilbert/optim.py"                  # ... and optimizer
     assert got["loader_file"].startswith(ref_loader.REFERENCE_ROOT)                        # the reference's datasets package
-    assert got["tblogger_file"] == "vilbert._reference_utils"                              # the reference's tbLogger
+    assert got["tblogger_file"] == os.path.join(ref_loader.REFERENCE_ROOT, "vilbert", "utils.py")   # the reference's tbLogger
     assert {"pytorch_model_0.bin", "pytorch_ckpt_0.tar", "command.txt"} <= set(got["files_written"])
     # the checkpoint the script wrote loads back into a fresh model of this package, key for key
     sys.path.insert(0, PKG)

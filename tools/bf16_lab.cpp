@@ -168,7 +168,7 @@ static int check_linear(int M, int N, int K) {
     for (const Variant& v : variants) {
         vb_linear_bf16_args g{};
         g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.M = M; g.N = N; g.K = K;
-        g.bias = v.bias ? dbias : nullptr;
+        g.bias[0] = v.bias ? dbias : nullptr;
         if (v.f32) { g.C32 = dC32; g.ldc32 = N; } else { g.C = dC; g.ldc = N; }
         if (v.res) { g.residual = dR; g.ldr = N; }
         if (v.mul) { g.mul = dR; g.ldm = N; }
@@ -224,10 +224,13 @@ static int check_wgrad(int M, int nseg, int seg_n, int K) {
     float* dW = to_dev(init);
     vb_wgrad_bf16_args g{};
     g.dY = dY; g.ldy = N; g.X = dX; g.ldx = K; g.M = M; g.K = K; g.nseg = nseg; g.seg_n = seg_n; g.ldw = K;
-    for (int s = 0; s < nseg; ++s) g.dW[s] = dW + (size_t)s * seg_n * K;
+    std::vector<float> binit(N, 0.25f);
+    float* dB = to_dev(binit);
+    for (int s = 0; s < nseg; ++s) { g.dW[s] = dW + (size_t)s * seg_n * K; g.dbias[s] = dB + (size_t)s * seg_n; }
     VB(vb_wgrad_bf16(nullptr, &g));
     CK(hipDeviceSynchronize());
     auto got = to_host(dW, (size_t)N * K);
+    auto gotb = to_host(dB, (size_t)N);
     long nbad = 0;
     double worst = 0;
     const int samples = 6000;
@@ -251,13 +254,17 @@ static int check_wgrad(int M, int nseg, int seg_n, int K) {
     VB(vb_colsum_bf16(nullptr, M, N, dY, N, dcs, dws));
     CK(hipDeviceSynchronize());
     auto cs = to_host(dcs, N);
-    long cbad = 0;
+    long cbad = 0, fbad = 0;
     for (int n = 0; n < N; ++n) {
-        double s = 0.5, m = 0;
+        double s = 0, m = 0;
         for (int r = 0; r < M; ++r) { s += bf16_val(Y[(size_t)r * N + n]); m += fabs(bf16_val(Y[(size_t)r * N + n])); }
-        if (!(fabs(cs[n] - s) <= 3e-6 * m + 1e-5)) ++cbad;
+        if (!(fabs(cs[n] - (s + 0.5)) <= 3e-6 * m + 1e-5)) ++cbad;
+        if (!(fabs(gotb[n] - (s + 0.25)) <= 3e-6 * m + 1e-5)) { if (fbad < 3) printf("    dbias[%d] = %g, want %g\n", n, gotb[n], s + 0.25); ++fbad; }
     }
-    printf("  %d sampled dW elements: worst err / tol %.3f %s; column sums %s\n", samples, worst, nbad ? "FAIL" : "ok", cbad ? "FAIL" : "ok");
+    printf("  %d sampled dW elements: worst err / tol %.3f %s; fused bias gradient %s; vb_colsum_bf16 %s\n", samples, worst,
+           nbad ? "FAIL" : "ok", fbad ? "FAIL" : "ok", cbad ? "FAIL" : "ok");
+    CK(hipFree(dB));
+    nbad += fbad;
     CK(hipFree(dY)); CK(hipFree(dX)); CK(hipFree(dW)); CK(hipFree(dcs)); CK(hipFree(dws));
     return (nbad != 0) + (cbad != 0);
 }
@@ -327,11 +334,11 @@ static void time_all() {
     printf("---- vb_linear_bf16 (forward / dgrad launches), random data\n");
     for (const S& s : shapes) {
         vb_linear_bf16_args g{};
-        g.A = dA; g.lda = s.K; g.W = dW; g.ldw = s.K; g.M = s.M; g.N = s.N; g.K = s.K; g.C = dC; g.ldc = s.N; g.bias = dbias;
+        g.A = dA; g.lda = s.K; g.W = dW; g.ldw = s.K; g.M = s.M; g.N = s.N; g.K = s.K; g.C = dC; g.ldc = s.N; g.bias[0] = dbias;
         if (s.epi == 1) { g.act = VB_ACT_GELU; g.act_grad = dD; g.ldg = s.N; }
         if (s.epi == 2) { g.residual = dR; g.ldr = s.N; g.dropout_p = 0.1f; g.seed = 7; }
-        if (s.epi == 3) { g.mul = dR; g.ldm = s.N; g.bias = nullptr; }
-        if (s.epi == 4) { g.residual = dR; g.ldr = s.N; g.bias = nullptr; }
+        if (s.epi == 3) { g.mul = dR; g.ldm = s.N; g.bias[0] = nullptr; }
+        if (s.epi == 4) { g.residual = dR; g.ldr = s.N; g.bias[0] = nullptr; }
         const double us = time_us([&] { VB(vb_linear_bf16(nullptr, &g)); }, 20);
         printf("  %-34s %5d x %4d x %4d  %3d tiles  %8.1f us  %7.1f TFLOP/s\n", s.what, s.M, s.N, s.K, ((s.M + 255) / 256) * (s.N / 128), us,
                2.0 * s.M * s.N * s.K / us * 1e-6);

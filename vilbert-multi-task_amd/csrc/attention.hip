@@ -31,14 +31,38 @@
 
 namespace {
 
+// The file is compiled twice (csrc/Makefile): as is - fp32 tensors, vb_attention_fwd / vb_attention_bwd - and with
+// -DVB_ATTN_BF16 - the bf16 training path: Q, K, V, dO read and O, dQ, dK, dV written as bf16 (half the HBM bytes of
+// kernels that are HBM-bound at these sequence lengths), vb_attention_fwd_bf16 / vb_attention_bwd_bf16. The arithmetic
+// is the same in both: operands are widened to fp32 on their way into registers / LDS, fp32 MFMA, fp32 softmax
+// statistics (mask, lse, D vector and the optional probabilities stay fp32 tensors).
+#ifdef VB_ATTN_BF16
+typedef unsigned short io_t;
+__device__ __forceinline__ f32x4 ld4(const io_t* p) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                 __uint_as_float(w.y & 0xffff0000u)};
+}
+__device__ __forceinline__ float ld1(const io_t* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void st1(io_t* p, float v) {
+    const unsigned u = __float_as_uint(v);
+    *p = (io_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+#else
+typedef float io_t;
+__device__ __forceinline__ f32x4 ld4(const io_t* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float ld1(const io_t* p) { return *p; }
+__device__ __forceinline__ void st1(io_t* p, float v) { *p = v; }
+#endif
+
 struct AttnP {
     int batch, heads, n_q, n_k, n_qt, n_kt;
     long q_bstride, kv_bstride, m_bstride;  // rows (or mask floats) per sample; 0 = broadcast
-    const float* Q; long ldq;
-    const float* K; long ldk;
-    const float* V; long ldv;
+    const io_t* Q; long ldq;
+    const io_t* K; long ldk;
+    const io_t* V; long ldv;
     const float* mask;
-    float* O; long ldo;
+    io_t* O; long ldo;
     float* probs;
     float* lse;       // [batch, heads, n_q]   forward: out (optional), backward: in
     float scale;
@@ -47,17 +71,17 @@ struct AttnP {
     const uint64_t* epoch;   // device step counter mixed into the seed (vb_set_seed_epoch), may be null
     long total;       // wave items
     // backward only
-    const float* dO; long lddo;
-    float* dQ; long lddq;
-    float* dK; long lddk;
-    float* dV; long lddv;
+    const io_t* dO; long lddo;
+    io_t* dQ; long lddq;
+    io_t* dK; long lddk;
+    io_t* dV; long lddv;
     float* dvec;      // [batch, heads, n_q]  D = rowsum(P dP): pass 1 out, pass 2 in
 };
 
 template <int DS>
-__device__ __forceinline__ void load_frag(f32x4 (&f)[DS], const float* p) {
+__device__ __forceinline__ void load_frag(f32x4 (&f)[DS], const io_t* p) {
 #pragma unroll
-    for (int s = 0; s < DS; ++s) f[s] = *reinterpret_cast<const f32x4*>(p + 16 * s);
+    for (int s = 0; s < DS; ++s) f[s] = ld4(p + 16 * s);
 }
 
 template <int DS>
@@ -102,8 +126,8 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
     f32x4 qf[DS];
     load_frag<DS>(qf, p.Q + ((long)b * p.q_bstride + q_row) * p.ldq + h * D + 4 * g);
 
-    const float* kbase = p.K + (long)b * p.kv_bstride * p.ldk + h * D;
-    const float* vbase = p.V + (long)b * p.kv_bstride * p.ldv + h * D;
+    const io_t* kbase = p.K + (long)b * p.kv_bstride * p.ldk + h * D;
+    const io_t* vbase = p.V + (long)b * p.kv_bstride * p.ldv + h * D;
     const float* mrow = p.mask != nullptr ? p.mask + (long)b * p.m_bstride : nullptr;
     const long prow = (bh * p.n_q + q_row) * p.n_k;  // element index of P[b, h, q, 0]
 
@@ -211,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
     }
 
     // forward: O[q][d] = sum_key P[q][key] V[key][d];  backward: dQ[q][d] = sum_key dS[q][key] K[key][d]
-    const float* rbase = (BWD ? kbase : vbase) + c;
+    const io_t* rbase = (BWD ? kbase : vbase) + c;
     const long ldr = BWD ? p.ldk : p.ldv;
     f32x4 oacc[DS];
 #pragma unroll
@@ -222,10 +246,10 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = min(kt * 16 + 4 * g + r, p.n_k - 1);  // the A operand is 0 past n_k
-                const float* rp = rbase + (long)key * ldr;
+                const io_t* rp = rbase + (long)key * ldr;
                 float vv[DS];
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
+                for (int dt = 0; dt < DS; ++dt) vv[dt] = ld1(rp + 16 * dt);
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt)
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
@@ -234,15 +258,15 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
     }
 
     // D[row = q = 4g + r][col = d = 16 dt + c]
-    float* obase = BWD ? p.dQ : p.O;
+    io_t* obase = BWD ? p.dQ : p.O;
     const long ldo = BWD ? p.lddq : p.ldo;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int q = qt * 16 + 4 * g + r;
         if (q < p.n_q) {
-            float* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
+            io_t* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
 #pragma unroll
-            for (int dt = 0; dt < DS; ++dt) op[16 * dt] = oacc[dt][r];
+            for (int dt = 0; dt < DS; ++dt) st1(op + 16 * dt, oacc[dt][r]);
         }
     }
 }
@@ -271,8 +295,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
     load_frag<DS>(vf, p.V + ((long)b * p.n_k + k_row) * p.ldv + h * D + 4 * g);
     const float madd = p.mask != nullptr ? p.mask[(long)b * p.n_k + k_row] : 0.f;
 
-    const float* qbase = p.Q + (long)b * p.n_q * p.ldq + h * D;
-    const float* dobase = p.dO + (long)b * p.n_q * p.lddo + h * D;
+    const io_t* qbase = p.Q + (long)b * p.n_q * p.ldq + h * D;
+    const io_t* dobase = p.dO + (long)b * p.n_q * p.lddo + h * D;
     const float* lse = p.lse + bh * p.n_q;
     const float* dvec = p.dvec + bh * p.n_q;
 
@@ -314,13 +338,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = min(qt * 16 + 4 * g + r, p.n_q - 1);  // A operands are 0 past n_q
-            const float* dop = dobase + (long)q * p.lddo + c;
-            const float* qp = qbase + (long)q * p.ldq + c;
+            const io_t* dop = dobase + (long)q * p.lddo + c;
+            const io_t* qp = qbase + (long)q * p.ldq + c;
             float dov[DS], qv[DS];
 #pragma unroll
             for (int dt = 0; dt < DS; ++dt) {
-                dov[dt] = dop[16 * dt];
-                qv[dt] = qp[16 * dt];
+                dov[dt] = ld1(dop + 16 * dt);
+                qv[dt] = ld1(qp + 16 * dt);
             }
 #pragma unroll
             for (int dt = 0; dt < DS; ++dt) {
@@ -335,12 +359,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
     for (int r = 0; r < 4; ++r) {
         const int kk = kt * 16 + 4 * g + r;
         if (kk < p.n_k) {
-            float* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
-            float* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
+            io_t* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
+            io_t* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
 #pragma unroll
             for (int dt = 0; dt < DS; ++dt) {
-                kp[16 * dt] = dk[dt][r];
-                vp[16 * dt] = dv[dt][r];
+                st1(kp + 16 * dt, dk[dt][r]);
+                st1(vp + 16 * dt, dv[dt][r]);
             }
         }
     }
@@ -360,8 +384,8 @@ constexpr int LDS_MAX_ROWS = 48;
 // block the compiler emitted load -> s_waitcnt vmcnt(0) -> ds_write per 16 bytes: 12 dependent trips to HBM per block
 // at head_dim 128 - profiles/r03_attn_bench.txt).
 template <int D>
-__device__ __forceinline__ void stage_rows2(float* __restrict__ s0, const float* __restrict__ g0, long ld0,
-                                            float* __restrict__ s1, const float* __restrict__ g1, long ld1, int n_rows) {
+__device__ __forceinline__ void stage_rows2(float* __restrict__ s0, const io_t* __restrict__ g0, long ld0,
+                                            float* __restrict__ s1, const io_t* __restrict__ g1, long ld1, int n_rows) {
     // [n_rows][D] global (row stride ld) -> [LDS_MAX_ROWS][D + 4] LDS, rows >= n_rows zero-filled
     constexpr int V4 = D / 4, IT = (LDS_MAX_ROWS * V4 + 255) / 256;
     f32x4 r0[IT], r1[IT];
@@ -370,8 +394,8 @@ __device__ __forceinline__ void stage_rows2(float* __restrict__ s0, const float*
     for (int i = 0; i < IT; ++i) {
         const int f = threadIdx.x + 256 * i;
         const int r = min(f / V4, n_rows - 1), c4 = f % V4;
-        r0[i] = *reinterpret_cast<const f32x4*>(g0 + (long)r * ld0 + c4 * 4);
-        r1[i] = *reinterpret_cast<const f32x4*>(g1 + (long)r * ld1 + c4 * 4);
+        r0[i] = ld4(g0 + (long)r * ld0 + c4 * 4);
+        r1[i] = ld4(g1 + (long)r * ld1 + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -541,15 +565,15 @@ __global__ __launch_bounds__(256, 3) void attn_q_lds_kernel(const AttnP p_in) { 
                 }
             }
         }
-        float* obase = BWD ? p.dQ : p.O;
+        io_t* obase = BWD ? p.dQ : p.O;
         const long ldo = BWD ? p.lddq : p.ldo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + 4 * g + r;
             if (q < p.n_q) {
-                float* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
+                io_t* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) op[16 * dt] = oacc[dt][r];
+                for (int dt = 0; dt < DS; ++dt) st1(op + 16 * dt, oacc[dt][r]);
             }
         }
     }
@@ -636,12 +660,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
         for (int r = 0; r < 4; ++r) {
             const int kk = kt * 16 + 4 * g + r;
             if (kk < p.n_k) {
-                float* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
-                float* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
+                io_t* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
+                io_t* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt) {
-                    kp[16 * dt] = dk[dt][r];
-                    vp[16 * dt] = dv[dt][r];
+                    st1(kp + 16 * dt, dk[dt][r]);
+                    st1(vp + 16 * dt, dv[dt][r]);
                 }
             }
         }
@@ -681,10 +705,10 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
     {   // stage the four operand blocks (coalesced 16-byte loads, rows of D floats). ALL loads of a thread are issued
         // before the first LDS store: with runtime loop bounds the compiler kept one load -> wait -> store round per
         // iteration, i.e. ~10 dependent trips to HBM per block with only 8 waves per CU to hide them (round 3).
-        const float* gk = p.K + (long)b * p.n_k * p.ldk + h * D;
-        const float* gv = p.V + (long)b * p.n_k * p.ldv + h * D;
-        const float* gq = p.Q + (long)b * p.n_q * p.ldq + h * D;
-        const float* go = p.dO + (long)b * p.n_q * p.lddo + h * D;
+        const io_t* gk = p.K + (long)b * p.n_k * p.ldk + h * D;
+        const io_t* gv = p.V + (long)b * p.n_k * p.ldv + h * D;
+        const io_t* gq = p.Q + (long)b * p.n_q * p.ldq + h * D;
+        const io_t* go = p.dO + (long)b * p.n_q * p.lddo + h * D;
         constexpr int IT = (LDS_MAX_ROWS * V4 + 255) / 256;
         f32x4 rk[IT], rv[IT], rq[IT], ro[IT];
 #pragma unroll
@@ -692,12 +716,12 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
             const int f = threadIdx.x + 256 * i;
             const int r = f / V4, c4 = (f % V4) * 4;
             if (r < p.n_k) {
-                rk[i] = *reinterpret_cast<const f32x4*>(gk + (long)r * p.ldk + c4);
-                rv[i] = *reinterpret_cast<const f32x4*>(gv + (long)r * p.ldv + c4);
+                rk[i] = ld4(gk + (long)r * p.ldk + c4);
+                rv[i] = ld4(gv + (long)r * p.ldv + c4);
             }
             if (r < p.n_q) {
-                rq[i] = *reinterpret_cast<const f32x4*>(gq + (long)r * p.ldq + c4);
-                ro[i] = *reinterpret_cast<const f32x4*>(go + (long)r * p.lddo + c4);
+                rq[i] = ld4(gq + (long)r * p.ldq + c4);
+                ro[i] = ld4(go + (long)r * p.lddo + c4);
             }
         }
 #pragma unroll
@@ -796,9 +820,9 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + 4 * g + r;
             if (q < p.n_q) {
-                float* op = p.dQ + ((long)b * p.n_q + q) * p.lddq + h * D + c;
+                io_t* op = p.dQ + ((long)b * p.n_q + q) * p.lddq + h * D + c;
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) op[16 * dt] = oacc[dt][r];
+                for (int dt = 0; dt < DS; ++dt) st1(op + 16 * dt, oacc[dt][r]);
             }
         }
     }
@@ -851,12 +875,12 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
         for (int r = 0; r < 4; ++r) {
             const int kk = kt * 16 + 4 * g + r;
             if (kk < p.n_k) {
-                float* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
-                float* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
+                io_t* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
+                io_t* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt) {
-                    kp[16 * dt] = dk[dt][r];
-                    vp[16 * dt] = dv[dt][r];
+                    st1(kp + 16 * dt, dk[dt][r]);
+                    st1(vp + 16 * dt, dv[dt][r]);
                 }
             }
         }
@@ -921,14 +945,29 @@ int launch_kv(hipStream_t st, const AttnP& p) {
     return 0;
 }
 
-int fill_common(AttnP& p, const vb_attention_args* a) {
+#ifdef VB_ATTN_BF16
+typedef vb_attention_bf16_args attn_args_t;
+typedef vb_attention_bf16_grads attn_grads_t;
+#define VB_ATTN_FWD vb_attention_fwd_bf16
+#define VB_ATTN_BWD vb_attention_bwd_bf16
+constexpr unsigned IO_ALIGN = 7u;       // 4 bf16 per load
+#else
+typedef vb_attention_args attn_args_t;
+typedef vb_attention_grads attn_grads_t;
+#define VB_ATTN_FWD vb_attention_fwd
+#define VB_ATTN_BWD vb_attention_bwd
+constexpr unsigned IO_ALIGN = 15u;
+#endif
+inline bool io_aligned(const void* q) { return (reinterpret_cast<uintptr_t>(q) & IO_ALIGN) == 0; }
+
+int fill_common(AttnP& p, const attn_args_t* a) {
     if (a == nullptr || a->Q == nullptr || a->K == nullptr || a->V == nullptr) return VB_E_BADARG;
     if (a->batch <= 0 || a->heads <= 0 || a->n_q <= 0 || a->n_k <= 0) return VB_E_BADARG;
     if (a->n_k > VB_MAX_KEYS) return VB_E_RANGE;
     if ((a->q_batch != a->batch && a->q_batch != 1) || (a->kv_batch != a->batch && a->kv_batch != 1))
         return VB_E_BADARG;
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
-    if ((a->ldq | a->ldk | a->ldv) % 4 != 0 || !vb_aligned16(a->Q) || !vb_aligned16(a->K) || !vb_aligned16(a->V))
+    if ((a->ldq | a->ldk | a->ldv) % 4 != 0 || !io_aligned(a->Q) || !io_aligned(a->K) || !io_aligned(a->V))
         return VB_E_ALIGN;
     p.batch = a->batch; p.heads = a->heads; p.n_q = a->n_q; p.n_k = a->n_k;
     p.n_qt = (a->n_q + 15) / 16;
@@ -945,7 +984,7 @@ int fill_common(AttnP& p, const vb_attention_args* a) {
 
 }  // namespace
 
-extern "C" int vb_attention_fwd(void* stream, const vb_attention_args* a) {
+extern "C" int VB_ATTN_FWD(void* stream, const attn_args_t* a) {
     AttnP p{};
     if (int e = fill_common(p, a)) return e;
     if (a->O == nullptr) return VB_E_BADARG;
@@ -960,14 +999,14 @@ extern "C" int vb_attention_fwd(void* stream, const vb_attention_args* a) {
     }
 }
 
-extern "C" int vb_attention_bwd(void* stream, const vb_attention_args* a, const vb_attention_grads* gr) {
+extern "C" int VB_ATTN_BWD(void* stream, const attn_args_t* a, const attn_grads_t* gr) {
     AttnP p{};
     if (int e = fill_common(p, a)) return e;
     if (gr == nullptr || gr->dO == nullptr || gr->dQ == nullptr || gr->dK == nullptr || gr->dV == nullptr ||
         gr->dvec == nullptr || a->lse == nullptr)
         return VB_E_BADARG;
     if (a->q_batch != a->batch || a->kv_batch != a->batch) return VB_E_BADARG;  // no broadcast in training
-    if (gr->lddo % 4 != 0 || !vb_aligned16(gr->dO)) return VB_E_ALIGN;
+    if (gr->lddo % 4 != 0 || !io_aligned(gr->dO)) return VB_E_ALIGN;
     p.dO = gr->dO; p.lddo = gr->lddo;
     p.dQ = gr->dQ; p.lddq = gr->lddq; p.dK = gr->dK; p.lddk = gr->lddk; p.dV = gr->dV; p.lddv = gr->lddv;
     p.dvec = gr->dvec;

@@ -37,7 +37,11 @@ constexpr int HB_A = HB_BM * HB_ROWB;           // 32,768 bytes
 constexpr int HB_B = HB_BN * HB_ROWB;           // 16,384
 constexpr int HB_STAGE = HB_A + HB_B;           // 49,152
 constexpr int HB_LDS = HB_S * HB_STAGE;         // 147,456
-constexpr int HB_MFMA_WAVES = 8, HB_THREADS = 64 * (HB_MFMA_WAVES + 2);
+// loader waves per operand: ONE wave keeps at most 64 KiB of LDS-DMA in flight (vmcnt is a 6-bit counter) - at the ~1 us
+// an L2-side request takes under load that is ~30 GB/s per CU, a third of what the matrix pipe consumes at these tile sizes
+// (rocprofv3 of the first version: 1.5 us per K tile against 0.43 us of MFMA time, profiles/r05_bf16_lab_first_version.txt)
+constexpr int HB_LW = 2;
+constexpr int HB_MFMA_WAVES = 8, HB_THREADS = 64 * (HB_MFMA_WAVES + 2 * HB_LW);
 
 __device__ __forceinline__ unsigned short bf16_rne(float v) {
     const unsigned u = __float_as_uint(v);
@@ -81,7 +85,7 @@ struct HbP {
     int M, N, K;
     const unsigned short* A; long lda;     // elements
     const unsigned short* B; long ldb;
-    const float* bias;
+    const float* bias[VB_MAX_SEGMENTS]; int bseg;   // bias of output columns [s bseg, (s + 1) bseg); null = none
     const unsigned short* R; long ldr;     // residual or multiplier, bf16 [M, N]
     unsigned short* C; long ldc;
     float* C32; long ldc32;
@@ -90,6 +94,8 @@ struct HbP {
     float drop_p, drop_scale;
     uint64_t seed;
     const uint64_t* epoch;
+    int flags;   // laboratory (VB_BF16_FLAGS, timing only - results are garbage): 1 = no DMA, 2 = no MFMA, 4 = no fragment reads,
+                 // 8 = no epilogue
 };
 
 __device__ __forceinline__ bool hb_origin(const HbP& p, int b, int it, int grid, int& m0, int& n0) {
@@ -112,10 +118,11 @@ __device__ __forceinline__ bool hb_origin(const HbP& p, int b, int it, int grid,
 
 // Loader wave of one operand of the NT kernel: ND DMAs (8 tile rows of 128 bytes each) per K tile. LDS rows of 128 bytes,
 // the eight 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 (fragment ds_read_b128 conflict-free); the DMA writes
-// lane-linear, so the swizzle is applied on the SOURCE address. PERM (the W operand): LDS row 64 w + 32 j + k of the tile
-// holds W row 64 w + 2 k + j, so that lane k of the natural accumulator map owns the ADJACENT output columns 2 k, 2 k + 1.
-template <int ND, bool IS_A>
-__device__ __forceinline__ void hb_loader(const HbP& p, const unsigned lds0, const int lane, const int nk, const int rounds) {
+// lane-linear, so the swizzle is applied on the SOURCE address.
+template <int ND_ALL, bool IS_A>
+__device__ __forceinline__ void hb_loader(const HbP& p, const unsigned lds0, const int lane, const int nk, const int rounds,
+                                          const int widx) {
+    constexpr int ND = ND_ALL / HB_LW;             // this wave's share: DMAs widx, widx + HB_LW, ...
     const unsigned short* const mat = IS_A ? p.A : p.B;
     const long ld = IS_A ? p.lda : p.ldb;
     const int nrows = IS_A ? p.M : p.N;
@@ -130,17 +137,18 @@ __device__ __forceinline__ void hb_loader(const HbP& p, const unsigned lds0, con
         base = mat + (long)r0 * ld;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int row = 8 * i + (lane >> 3), slot = lane & 7;     // LDS row of this lane's 16 bytes
+            const int row = 8 * (HB_LW * i + widx) + (lane >> 3), slot = lane & 7;     // LDS row of this lane's 16 bytes
             const int chunk = slot ^ ((row >> 1) & 7);
-            const int grow = IS_A ? row : (row & 64) + 2 * (row & 31) + ((row >> 5) & 1);   // matrix row it holds
-            off[i] = (unsigned)((long)min(grow, nrows - 1 - r0) * ld * 2 + 16 * chunk);    // rows past the matrix: clamped, never stored
+            off[i] = (unsigned)((long)min(row, nrows - 1 - r0) * ld * 2 + 16 * chunk);    // rows past the matrix: clamped, never stored
         }
     };
     int it = 0, kt = 0, stage_w = 0;
     auto issue_next = [&]() {
         const unsigned l = lds0 + (unsigned)stage_w * HB_STAGE;
+        if (!(p.flags & 1)) {
 #pragma unroll
-        for (int i = 0; i < ND; ++i) hb_glds16(off[i], base, l + REG + 1024u * i);
+            for (int i = 0; i < ND; ++i) hb_glds16(off[i], base, l + REG + 1024u * (HB_LW * i + widx));
+        }
         base += HB_BK;
         stage_w = stage_w == HB_S - 1 ? 0 : stage_w + 1;
         if (++kt == nk) {
@@ -174,8 +182,9 @@ __global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= HB_MFMA_WAVES) {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-        if (wave == HB_MFMA_WAVES) hb_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, nk, rounds);
-        else hb_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, nk, rounds);
+        const int lw = wave - HB_MFMA_WAVES;
+        if (lw < HB_LW) hb_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, nk, rounds, lw);
+        else hb_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, nk, rounds, lw - HB_LW);
         return;
     }
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
     // which the instruction consumes its 16 k values cannot matter.
     auto read_set = [&](auto S_, const char* stage, int s) {
         constexpr int S = decltype(S_)::value;
+        if (p.flags & 4) return;
         const int co = ((2 * s + hi) ^ key) << 4;
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[S][i] = *reinterpret_cast<const bf16x8*>(stage + fa_off + i * 32 * HB_ROWB + co);
@@ -199,12 +209,14 @@ __global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
     };
     auto mfmas = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
+        if (p.flags & 2) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                // natural product: rows of the A fragment -> accumulator registers, rows of the W fragment -> lane & 31
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+                // TRANSPOSED product: rows of the W fragment -> accumulator registers (output columns), rows of the A fragment
+                // -> lane & 31 (output row): a lane owns ONE output row and 4-column groups of it
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j], fa[S][i], acc[i][j], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -262,58 +274,83 @@ __global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
         }
         int m0 = 0, n0 = 0;
         hb_origin(p, b, it, grid, m0, n0);
-        // ---- natural map: acc[i][j][r] = row m0 + wm 64 + 32 i + 4 hi + (r & 3) + 8 (r >> 2), column n0 + wn 64 + 2 l31 + j
-        const int col = n0 + wn * 64 + 2 * l31;
-        float2 bv = float2{0.f, 0.f};
-        if (p.bias != nullptr) bv = *reinterpret_cast<const float2*>(p.bias + col);
-        const bool full = m0 + HB_BM <= p.M;
+        if (p.flags & 8) continue;
+        // ---- Epilogue on the transposed map: lane (l31, hi) holds output row m0 + wm 64 + 32 i + l31 of tile (i, j) and its
+        // columns nw + 32 j + 8 q + 4 hi + e (e = 0..3) in acc[i][j][4 q + e]. The epilogue of a persistent block is bound by
+        // store ISSUE (~7 B/clk/CU with 4-byte stores: cdna guide T21), not by bandwidth - so the bf16 results leave as 16-byte
+        // stores: the two half-waves of a row trade their 4-column pieces of two adjacent 8-column groups
+        // (v_permlane32_swap), after which every lane owns 8 consecutive columns. The second [M, N] operand (residual /
+        // multiplier) arrives the same way in reverse: one 16-byte load per two groups, then the same swap.
+        const int nw = n0 + wn * 64;
         const uint64_t seed = EPI == HB_DROPRES ? vb_seed_with_epoch(p.seed, p.epoch) : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int rbase = m0 + wm * 64 + 32 * i + 4 * hi;
-            unsigned rw[16];
-            if (EPI == HB_RES || EPI == HB_DROPRES || EPI == HB_MUL) {
+            const int m = m0 + wm * 64 + 32 * i + l31;
+            const bool live = m < p.M;
+            const long mr = live ? m : p.M - 1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)   // clamped, never predicated (a per-element branch serialises the loads)
-                    rw[r] = *reinterpret_cast<const unsigned*>(p.R + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col);
-            }
-            float2 v[16], d[16];
+            for (int j = 0; j < 2; ++j) {
+                const int nb = nw + 32 * j;
+                const int bs = nb / p.bseg;                                   // (a 32-column block never straddles segments)
+                const float* __restrict__ bp = p.bias[bs] != nullptr ? p.bias[bs] + (nb - bs * p.bseg) : nullptr;
+                uint2 rq[4];
+                if (EPI == HB_RES || EPI == HB_DROPRES || EPI == HB_MUL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                v[r] = float2{acc[i][0][r] + bv.x, acc[i][1][r] + bv.y};
-                if (EPI == HB_GELU) {
-                    gelu_and_grad(v[r].x, v[r].x, d[r].x);
-                    gelu_and_grad(v[r].y, v[r].y, d[r].y);
+                    for (int kq = 0; kq < 4; kq += 2) {
+                        // lanes 0-31: columns 8 kq .. 8 kq + 7, lanes 32-63: the next eight
+                        uint4 t = *reinterpret_cast<const uint4*>(p.R + mr * p.ldr + nb + 8 * (kq + hi));
+                        const auto sx = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+                        rq[kq] = uint2{sx[0], sy[0]};
+                        rq[kq + 1] = uint2{sx[1], sy[1]};
+                    }
                 }
-                if (EPI == HB_RELU) v[r] = float2{fmaxf(v[r].x, 0.f), fmaxf(v[r].y, 0.f)};
-                if (EPI == HB_DROPRES) {
-                    const uint64_t idx = (uint64_t)((long)(rbase + (r & 3) + 8 * (r >> 2)) * p.N + col);
-                    v[r].x = vb_keep(seed, idx, p.drop_p) ? v[r].x * p.drop_scale : 0.f;
-                    v[r].y = vb_keep(seed, idx + 1, p.drop_p) ? v[r].y * p.drop_scale : 0.f;
+                uint2 o2[4], d2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (bp != nullptr) bv = *reinterpret_cast<const f32x4*>(bp + 8 * q + 4 * hi);
+                    f32x4 v, d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[i][j][4 * q + e] + bv[e];
+                        if (EPI == HB_GELU) {
+                            float gy, gd;
+                            gelu_and_grad(x, gy, gd);
+                            x = gy;
+                            d[e] = gd;
+                        }
+                        if (EPI == HB_RELU) x = fmaxf(x, 0.f);
+                        if (EPI == HB_DROPRES) {
+                            const uint64_t idx = (uint64_t)((long)m * p.N + nb + 8 * q + 4 * hi + e);
+                            x = vb_keep(seed, idx, p.drop_p) ? x * p.drop_scale : 0.f;
+                        }
+                        v[e] = x;
+                    }
+                    if (EPI == HB_RES || EPI == HB_DROPRES)
+                        v += f32x4{bf16_lo(rq[q].x), bf16_hi(rq[q].x), bf16_lo(rq[q].y), bf16_hi(rq[q].y)};
+                    if (EPI == HB_MUL) v *= f32x4{bf16_lo(rq[q].x), bf16_hi(rq[q].x), bf16_lo(rq[q].y), bf16_hi(rq[q].y)};
+                    if (OUT == HB_OUT_F32) {
+                        if (live) *reinterpret_cast<f32x4*>(p.C32 + (long)m * p.ldc32 + nb + 8 * q + 4 * hi) = v;
+                    } else {
+                        o2[q] = uint2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                        if (EPI == HB_GELU) d2[q] = uint2{pack_bf16(d[0], d[1]), pack_bf16(d[2], d[3])};
+                    }
                 }
-                if (EPI == HB_RES || EPI == HB_DROPRES) v[r] = float2{v[r].x + bf16_lo(rw[r]), v[r].y + bf16_hi(rw[r])};
-                if (EPI == HB_MUL) v[r] = float2{v[r].x * bf16_lo(rw[r]), v[r].y * bf16_hi(rw[r])};
-            }
-            if (OUT == HB_OUT_F32) {
-                float* __restrict__ cp = p.C32 + (long)rbase * p.ldc32 + col;
+                if (OUT == HB_OUT_BF16) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (full || rbase + (r & 3) + 8 * (r >> 2) < p.M)
-                        *reinterpret_cast<float2*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc32) = v[r];
-            } else {
-                unsigned short* __restrict__ cp = p.C + (long)rbase * p.ldc + col;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (full || rbase + (r & 3) + 8 * (r >> 2) < p.M)
-                        *reinterpret_cast<unsigned*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc) = pack_bf16(v[r].x, v[r].y);
-            }
-            if (EPI == HB_GELU) {
-                if (p.D != nullptr) {
-                    unsigned short* __restrict__ dp = p.D + (long)rbase * p.ldd + col;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (full || rbase + (r & 3) + 8 * (r >> 2) < p.M)
-                            *reinterpret_cast<unsigned*>(dp + (long)((r & 3) + 8 * (r >> 2)) * p.ldd) = pack_bf16(d[r].x, d[r].y);
+                    for (int kq = 0; kq < 4; kq += 2) {
+                        const auto sx = __builtin_amdgcn_permlane32_swap(o2[kq].x, o2[kq + 1].x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(o2[kq].y, o2[kq + 1].y, false, false);
+                        if (live) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + nb + 8 * (kq + hi)) = uint4{sx[0], sy[0], sx[1], sy[1]};
+                        if (EPI == HB_GELU) {
+                            if (p.D != nullptr) {
+                                const auto dx = __builtin_amdgcn_permlane32_swap(d2[kq].x, d2[kq + 1].x, false, false);
+                                const auto dy = __builtin_amdgcn_permlane32_swap(d2[kq].y, d2[kq + 1].y, false, false);
+                                if (live) *reinterpret_cast<uint4*>(p.D + (long)m * p.ldd + nb + 8 * (kq + hi)) = uint4{dx[0], dy[0], dx[1], dy[1]};
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -354,9 +391,11 @@ struct HwP {
     const unsigned short* Y; long ldy;
     const unsigned short* X; long ldx;
     float* C[VB_MAX_SEGMENTS]; long ldc; int cseg;
+    float* bias[VB_MAX_SEGMENTS];   // bias gradient of the segment (column sums of dY), ADDED into; may be null
     int tiles_k, tiles;             // tiles = (N / 256) (K / 128)
     int nkt, kt_per_split, splits;  // contraction tiles in total / per unit, units per tile
     int units;
+    int flags;                      // laboratory (VB_BF16_FLAGS), as HbP
 };
 
 __device__ __forceinline__ void hw_unit(const HwP& p, int u, int& n0, int& k0, int& kt0, int& nk) {
@@ -367,8 +406,9 @@ __device__ __forceinline__ void hw_unit(const HwP& p, int u, int& n0, int& k0, i
     nk = min(p.kt_per_split, p.nkt - kt0);
 }
 
-template <int ND, bool IS_A>
-__device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, const int lane, const int n_units) {
+template <int ND_ALL, bool IS_A>
+__device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, const int lane, const int n_units, const int widx) {
+    constexpr int ND = ND_ALL / HB_LW;
     const unsigned short* const mat = IS_A ? p.Y : p.X;
     const long ld = IS_A ? p.ldy : p.ldx;
     constexpr unsigned REG = IS_A ? 0u : (unsigned)HB_A;
@@ -378,7 +418,7 @@ __device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, con
     const int sub = lane / CPR, cp = lane % CPR;   // row inside the DMA's rows, physical chunk
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-        const int m = RPD * i + sub;
+        const int m = RPD * (HB_LW * i + widx) + sub;
         off[i] = (unsigned)((long)m * ld * 2 + 16 * (cp ^ ((m & 3) << 2)));
     }
     const unsigned short* base = nullptr;
@@ -398,17 +438,18 @@ __device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, con
     auto issue_next = [&]() {
         const unsigned l = lds0 + (unsigned)stage_w * HB_STAGE;
         const int rows_left = p.M - (kt0 + kt) * HB_BK;
-        if (rows_left >= HB_BK) {
+        if (p.flags & 1) {
+        } else if (rows_left >= HB_BK) {
 #pragma unroll
-            for (int i = 0; i < ND; ++i) hb_glds16(off[i], base, l + REG + 1024u * i);
+            for (int i = 0; i < ND; ++i) hb_glds16(off[i], base, l + REG + 1024u * (HB_LW * i + widx));
         } else {
             // the last contraction tile of a ragged M: rows past the end are fetched from the last real row (finite
             // data; the MFMA waves zero the dY fragment elements of those rows)
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
-                const int m = RPD * i + sub;
+                const int m = RPD * (HB_LW * i + widx) + sub;
                 const unsigned o = (unsigned)((long)min(m, rows_left - 1) * ld * 2 + 16 * (cp ^ ((m & 3) << 2)));
-                hb_glds16(o, base, l + REG + 1024u * i);
+                hb_glds16(o, base, l + REG + 1024u * (HB_LW * i + widx));
             }
         }
         base += (long)HB_BK * ld;
@@ -438,8 +479,9 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= HB_MFMA_WAVES) {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-        if (wave == HB_MFMA_WAVES) hw_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, n_units);
-        else hw_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, n_units);
+        const int lw = wave - HB_MFMA_WAVES;
+        if (lw < HB_LW) hw_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, n_units, lw);
+        else hw_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, n_units, lw - HB_LW);
         return;
     }
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -463,6 +505,7 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
     };
     auto read_set = [&](auto S_, unsigned stage, int s) {
         constexpr int S = decltype(S_)::value;
+        if (p.flags & 4) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bf16x4 lo = tr(stage + a_addr[i] + (unsigned)(16 * s) * HW_ROWA);
@@ -493,11 +536,27 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
     };
     auto mfmas = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
+        if (p.flags & 2) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+    };
+    // Bias gradient = column sums of dY over this unit's rows, for free: the waves of k column 0 (wn == 0) of the units of
+    // k tile 0 already hold every dY element of their 64 columns in their A fragments - lane (l31, hi) the 8 rows of column
+    // l31 of a step - and add them up with VALU instructions that issue beside the MFMAs.
+    float bsum[2] = {0.f, 0.f};
+    auto bias_acc = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const v4i w = __builtin_bit_cast(v4i, fa[S][i]);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t += bf16_lo((unsigned)w[e]) + bf16_hi((unsigned)w[e]);
+            bsum[i] += t;
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -507,6 +566,7 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
     for (int ui = 0; ui < n_units; ++ui) {
         int n0, k0, kt0, nk;
         hw_unit(p, b + ui * grid, n0, k0, kt0, nk);
+        const bool do_bias = k0 == 0 && wn == 0 && p.bias[n0 / p.cseg] != nullptr;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -525,20 +585,24 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
             read_set(I1{}, cur, 1);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I0{});
+            if (do_bias) bias_acc(I0{});
             __builtin_amdgcn_sched_barrier(0);
             read_set(I0{}, cur, 2);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I1{});
+            if (do_bias) bias_acc(I1{});
             __builtin_amdgcn_sched_barrier(0);
             read_set(I1{}, cur, 3);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I0{});
+            if (do_bias) bias_acc(I0{});
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             read_set(I0{}, nxt, 0);
             if (ragged && kt + 2 == nk) mask_set(I0{}, 0, last_rows);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I1{});
+            if (do_bias) bias_acc(I1{});
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -548,21 +612,26 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
             if (ragged) mask_set(I1{}, 1, last_rows);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I0{});
+            if (do_bias) bias_acc(I0{});
             __builtin_amdgcn_sched_barrier(0);
             read_set(I0{}, cur, 2);
             if (ragged) mask_set(I0{}, 2, last_rows);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I1{});
+            if (do_bias) bias_acc(I1{});
             __builtin_amdgcn_sched_barrier(0);
             read_set(I1{}, cur, 3);
             if (ragged) mask_set(I1{}, 3, last_rows);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(I0{});
+            if (do_bias) bias_acc(I0{});
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             mfmas(I1{});
+            if (do_bias) bias_acc(I1{});
         }
         // acc[i][j][rr]: n = n0 + wm 64 + 32 i + 4 hi + (rr & 3) + 8 (rr >> 2), k = k0 + wn 64 + 32 j + l31
+        if (p.flags & 8) continue;
         const int seg = n0 / p.cseg;
         float* __restrict__ cb = p.C[seg] + (long)(n0 - seg * p.cseg + wm * 64 + 4 * hi) * p.ldc + k0 + wn * 64 + l31;
 #pragma unroll
@@ -572,6 +641,14 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr)
                     unsafeAtomicAdd(cb + (long)(32 * i + (rr & 3) + 8 * (rr >> 2)) * p.ldc + 32 * j, acc[i][j][rr]);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float t = bsum[i] + __shfl_xor(bsum[i], 32);
+                if (hi == 0) unsafeAtomicAdd(p.bias[seg] + (n0 - seg * p.cseg + wm * 64 + 32 * i + l31), t);
+                bsum[i] = 0.f;
+            }
+        }
     }
 }
 
@@ -630,6 +707,39 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(int rows, int cols, 
     }
 }
 
+// the same for EVERY registered weight in one launch (once per optimizer step): block b finds its segment in the table by
+// bisection over the segments' first tile
+__global__ __launch_bounds__(256) void weight_shadow_multi_kernel(int n_segs, const vb_shadow_seg* __restrict__ tab) {
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = n_segs - 1;
+    const long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const vb_shadow_seg sg = tab[lo];
+    const int t = (int)(b - sg.tile0), tiles_c = sg.cols >> 6;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = tr + 16 * i;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sg.w + (long)(r0 + row) * sg.cols + c0 + tc);
+        const unsigned lo2 = pack_bf16(v[0], v[1]), hi2 = pack_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2*>(sg.w16 + (long)(r0 + row) * sg.ld16 + c0 + tc) = uint2{lo2, hi2};
+        tile[row][tc] = (unsigned short)lo2; tile[row][tc + 1] = (unsigned short)(lo2 >> 16);
+        tile[row][tc + 2] = (unsigned short)hi2; tile[row][tc + 3] = (unsigned short)(hi2 >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = tr + 16 * i;
+        const unsigned lo2 = (unsigned)tile[tc][col] | ((unsigned)tile[tc + 1][col] << 16);
+        const unsigned hi2 = (unsigned)tile[tc + 2][col] | ((unsigned)tile[tc + 3][col] << 16);
+        *reinterpret_cast<uint2*>(sg.wt16 + (long)(c0 + col) * sg.ldt + r0 + tc) = uint2{lo2, hi2};
+    }
+}
+
 // column sums of a bf16 [rows, cols] matrix (bias gradient): stage 1 - a block owns 256 columns x one row slab, a thread 4
 // columns of every fourth row, waves summed through LDS, one partial row per slab; stage 2 - the slabs in order
 // (deterministic). out: ADDED into (the gradient arena semantics of the weight gradients).
@@ -671,15 +781,17 @@ extern "C" int vb_linear_bf16(void* stream, const vb_linear_bf16_args* a) {
     if (a->K % HB_BK != 0 || a->N % HB_BN != 0) return VB_E_ALIGN;
     if (a->lda % 8 != 0 || a->ldw % 8 != 0 || a->lda < a->K || a->ldw < a->K || !vb_aligned16(a->A) || !vb_aligned16(a->W))
         return VB_E_ALIGN;
-    if (a->C != nullptr && (a->ldc % 2 != 0 || a->ldc < a->N || (reinterpret_cast<uintptr_t>(a->C) & 3u) != 0)) return VB_E_ALIGN;
-    if (a->C32 != nullptr && (a->ldc32 % 2 != 0 || a->ldc32 < a->N || (reinterpret_cast<uintptr_t>(a->C32) & 7u) != 0)) return VB_E_ALIGN;
-    if (a->bias != nullptr && (reinterpret_cast<uintptr_t>(a->bias) & 7u) != 0) return VB_E_ALIGN;
+    if (a->C != nullptr && (a->ldc % 8 != 0 || a->ldc < a->N || !vb_aligned16(a->C))) return VB_E_ALIGN;
+    if (a->C32 != nullptr && (a->ldc32 % 4 != 0 || a->ldc32 < a->N || !vb_aligned16(a->C32))) return VB_E_ALIGN;
+    const int nbias = a->bias_segments > 0 ? a->bias_segments : 1;
+    if (nbias > VB_MAX_SEGMENTS || a->N % nbias != 0 || (a->N / nbias) % 32 != 0) return VB_E_SEGMENT;
+    for (int s = 0; s < nbias; ++s)
+        if (a->bias[s] != nullptr && !vb_aligned16(a->bias[s])) return VB_E_ALIGN;
     if (a->residual != nullptr && a->mul != nullptr) return VB_E_BADARG;
     const uint16_t* second = a->residual != nullptr ? a->residual : a->mul;
     const int64_t ld2 = a->residual != nullptr ? a->ldr : a->ldm;
-    if (second != nullptr && (ld2 % 2 != 0 || ld2 < a->N || (reinterpret_cast<uintptr_t>(second) & 3u) != 0)) return VB_E_ALIGN;
-    if (a->act_grad != nullptr && (a->ldg % 2 != 0 || a->ldg < a->N || (reinterpret_cast<uintptr_t>(a->act_grad) & 3u) != 0))
-        return VB_E_ALIGN;
+    if (second != nullptr && (ld2 % 8 != 0 || ld2 < a->N || !vb_aligned16(second))) return VB_E_ALIGN;
+    if (a->act_grad != nullptr && (a->ldg % 8 != 0 || a->ldg < a->N || !vb_aligned16(a->act_grad))) return VB_E_ALIGN;
     if (a->act != VB_ACT_NONE && a->act != VB_ACT_GELU && a->act != VB_ACT_RELU) return VB_E_BADARG;
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return VB_E_BADARG;
     if (a->lda * 2 * 256 > 0xffffffffL || a->ldw * 2 * 256 > 0xffffffffL) return VB_E_RANGE;
@@ -691,7 +803,8 @@ extern "C" int vb_linear_bf16(void* stream, const vb_linear_bf16_args* a) {
     HbP p{};
     p.M = (int)a->M; p.N = (int)a->N; p.K = (int)a->K;
     p.A = a->A; p.lda = a->lda; p.B = a->W; p.ldb = a->ldw;
-    p.bias = a->bias;
+    for (int s = 0; s < nbias; ++s) p.bias[s] = a->bias[s];
+    p.bseg = p.N / nbias;
     p.R = second; p.ldr = ld2;
     p.C = a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;
     p.D = a->act_grad; p.ldd = a->ldg;
@@ -701,6 +814,8 @@ extern "C" int vb_linear_bf16(void* stream, const vb_linear_bf16_args* a) {
     p.drop_scale = drop ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
     p.seed = a->seed;
     p.epoch = vb_seed_epoch();
+    static const int lab_flags = [] { const char* e = getenv("VB_BF16_FLAGS"); return e ? atoi(e) : 0; }();
+    p.flags = lab_flags;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (a->C32 != nullptr) {
         if (a->act == VB_ACT_GELU || drop || a->mul != nullptr) return VB_E_BADARG;
@@ -730,6 +845,7 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     for (int s = 0; s < a->nseg; ++s) {
         if (a->dW[s] == nullptr || (reinterpret_cast<uintptr_t>(a->dW[s]) & 3u) != 0) return VB_E_BADARG;
         p.C[s] = a->dW[s];
+        p.bias[s] = a->dbias[s];
     }
     p.ldc = a->ldw; p.cseg = a->seg_n;
     p.tiles_k = p.K / HB_BN;
@@ -744,6 +860,8 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     p.kt_per_split = (p.nkt + splits - 1) / splits;
     p.splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
     p.units = p.tiles * p.splits;
+    static const int lab_flags = [] { const char* e = getenv("VB_BF16_FLAGS"); return e ? atoi(e) : 0; }();
+    p.flags = lab_flags;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
     if (attr != hipSuccess) return (int)attr;
@@ -781,6 +899,14 @@ extern "C" int vb_weight_shadow_bf16(void* stream, int32_t rows, int32_t cols, c
     if (wt16 != nullptr && (ldt % 4 != 0 || ldt < rows || (reinterpret_cast<uintptr_t>(wt16) & 7u) != 0)) return VB_E_ALIGN;
     hipLaunchKernelGGL(weight_shadow_kernel, dim3(cols / 64, rows / 64), dim3(256), 0, static_cast<hipStream_t>(stream), rows, cols,
                        w, (long)ldw, w16, (long)ld16, wt16, (long)ldt);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_weight_shadow_multi(void* stream, int32_t n_segs, const vb_shadow_seg* table, int64_t total_tiles) {
+    if (table == nullptr || n_segs <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffL) return VB_E_BADARG;
+    hipLaunchKernelGGL(weight_shadow_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), n_segs,
+                       table);
     VB_LAUNCH_CHECK();
     return 0;
 }

@@ -81,7 +81,7 @@ class LinearBf16Args(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("lda", ctypes.c_int64),
         ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
-        ("bias", _c_f32p),
+        ("bias", _c_f32p * VB_MAX_SEGMENTS), ("bias_segments", ctypes.c_int32),
         ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64),
         ("C32", _c_f32p), ("ldc32", ctypes.c_int64),
         ("residual", ctypes.c_void_p), ("ldr", ctypes.c_int64),
@@ -100,6 +100,7 @@ class WgradBf16Args(ctypes.Structure):
         ("dY", ctypes.c_void_p), ("ldy", ctypes.c_int64),
         ("X", ctypes.c_void_p), ("ldx", ctypes.c_int64),
         ("dW", _c_f32p * VB_MAX_SEGMENTS), ("ldw", ctypes.c_int64),
+        ("dbias", _c_f32p * VB_MAX_SEGMENTS),
         ("M", ctypes.c_int64), ("K", ctypes.c_int64),
         ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32),
     ]
@@ -122,7 +123,7 @@ class AttentionMxArgs(ctypes.Structure):
 
 
 class AttentionArgs(ctypes.Structure):
-    """vb_attention_args"""
+    """vb_attention_args (and vb_attention_bf16_args: the same layout, bf16 tensors behind Q / K / V / O)"""
     _fields_ = [
         ("batch", ctypes.c_int32), ("heads", ctypes.c_int32), ("head_dim", ctypes.c_int32),
         ("n_q", ctypes.c_int32), ("n_k", ctypes.c_int32),
@@ -141,7 +142,7 @@ class AttentionArgs(ctypes.Structure):
 
 
 class AttentionGrads(ctypes.Structure):
-    """vb_attention_grads"""
+    """vb_attention_grads (and vb_attention_bf16_grads)"""
     _fields_ = [
         ("dO", _c_f32p), ("lddo", ctypes.c_int64),
         ("dQ", _c_f32p), ("lddq", ctypes.c_int64),
@@ -244,11 +245,14 @@ SIGNATURES = {
     "vb_kl_fwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _F32, _P, _P, _P, _P, _P]),
     "vb_kl_bwd": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _I64, _P]),
     "vb_concap_finish_batch": (ctypes.c_int, [_P, ctypes.POINTER(ConcapBatch)]),
+    "vb_attention_fwd_bf16": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs)]),
+    "vb_attention_bwd_bf16": (ctypes.c_int, [_P, ctypes.POINTER(AttentionArgs), ctypes.POINTER(AttentionGrads)]),
     "vb_linear_bf16": (ctypes.c_int, [_P, ctypes.POINTER(LinearBf16Args)]),
     "vb_wgrad_bf16": (ctypes.c_int, [_P, ctypes.POINTER(WgradBf16Args)]),
     "vb_colsum_bf16_workspace": (_I64, [_I32]),
     "vb_colsum_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _P]),
     "vb_weight_shadow_bf16": (ctypes.c_int, [_P, _I32, _I32, _P, _I64, _P, _I64, _P, _I64]),
+    "vb_weight_shadow_multi": (ctypes.c_int, [_P, _I32, _P, _I64]),
     "vb_cast_f32_bf16": (ctypes.c_int, [_P, _I64, _P, _P]),
     "vb_cast_bf16_f32": (ctypes.c_int, [_P, _I64, _P, _P]),
     "vb_layernorm_fwd_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _F32, _P, _P, _P]),
@@ -277,6 +281,8 @@ def lib():
         if os.environ.get("VB_GEMM_MODE") in ("fp8", "mxfp8"):
             _FP8["on"] = True
             _FP8["mx"] = os.environ.get("VB_GEMM_MODE") == "mxfp8"
+        if os.environ.get("VB_GEMM_MODE") == "bf16":
+            _BF16["stream"] = os.environ.get("VB_BF16_STREAM", "1") != "0"
     return _lib
 
 
@@ -362,6 +368,7 @@ def set_gemm_v4(mode):
 
 GEMM_MODES = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}
 _FP8 = {"on": False, "mx": False}
+_BF16 = {"stream": False}
 
 
 def set_gemm_mode(mode):
@@ -370,12 +377,18 @@ def set_gemm_mode(mode):
     "fp8": FORWARD linears whose shape allows it run on quantised e4m3 operands (vb_linear_fwd_fp8, host-side weight
     cache in ops.py); everything else - backward GEMMs, ineligible shapes - stays exact fp32;
     "fp8+bf16": fp8 forward as above, every other GEMM (backward, ineligible shapes) in the bf16 mode;
-    "mxfp8": as "fp8" with the MX block-scaled kernels wherever K % 128 == 0 and N % 128 == 0 (round 4; inference)."""
+    "mxfp8": as "fp8" with the MX block-scaled kernels wherever K % 128 == 0 and N % 128 == 0 (round 4; inference).
+    "bf16" (round 5) additionally switches the MODEL to the bf16 training / inference stream (`bf16_stream()`): the encoder's
+    activations, saved tensors and activation gradients are torch.bfloat16 tensors served by csrc/gemm_bf16.hip
+    (ops16.py) - the reference's `model.half()` mode; launches that still see fp32 tensors (heads, embeddings, ineligible
+    shapes) run on the C side's bf16-operand kernels as before. VB_BF16_STREAM=0 keeps the round-2 behaviour (fp32
+    tensors everywhere, operands rounded on their way into LDS)."""
     if mode not in GEMM_MODES and mode not in ("fp8", "fp8+bf16", "mxfp8"):
         raise KeyError("unknown GEMM mode %r (f32 | bf16x6 | bf16x3 | bf16 | fp8 | fp8+bf16 | mxfp8)" % (mode,))
     prev_fp8, prev_mx = _FP8["on"], _FP8["mx"]
     _FP8["on"] = mode in ("fp8", "fp8+bf16", "mxfp8")
     _FP8["mx"] = mode == "mxfp8"
+    _BF16["stream"] = mode == "bf16" and os.environ.get("VB_BF16_STREAM", "1") != "0"
     prev = lib().vb_set_gemm_mode(GEMM_MODES["f32" if mode in ("fp8", "mxfp8") else "bf16" if mode == "fp8+bf16" else mode])
     prev_name = {v: k for k, v in GEMM_MODES.items()}[prev]
     if prev_mx:
@@ -387,6 +400,11 @@ def set_gemm_mode(mode):
 
 def fp8_enabled():
     return _FP8["on"]
+
+
+def bf16_stream():
+    """The model keeps its encoder activations in bfloat16 (set_gemm_mode("bf16"), round 5)."""
+    return _BF16["stream"]
 
 
 def mx_enabled():

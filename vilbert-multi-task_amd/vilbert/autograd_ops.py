@@ -110,8 +110,10 @@ class _Claims(object):
         return value
 
 
-def _wgrad(dy, x, weights, biases_present, need_w, need_b):
-    """dW / db of the stacked segments into their arena slices (or fresh buffers); returns what autograd gets."""
+def _wgrad(dy, x, weights, biases_present, need_w, need_b, launcher=None):
+    """dW / db of the stacked segments into their arena slices (or fresh buffers); returns what autograd gets.
+    launcher: ops.linear_bwd_weight (fp32 tensors, default) or ops16.linear_bwd_weight (bf16 tensors) - same contract."""
+    launcher = launcher or ops.linear_bwd_weight
     nseg, seg_n = len(weights), weights[0].shape[0]
     cw = _Claims(weights, need_w)
     cb = _Claims(biases_present, need_b)
@@ -122,14 +124,14 @@ def _wgrad(dy, x, weights, biases_present, need_w, need_b):
         ws.wait_stream(cur)
         N.set_stream(ws)
         try:
-            dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
+            dws, dbs = launcher(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
         finally:
             N.set_stream(cur)
         dy.record_stream(ws)
         x.record_stream(ws)
         _WGRAD["used"].setdefault(dy.device.index, {})[ws.cuda_stream] = ws
     else:
-        dws, dbs = ops.linear_bwd_weight(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
+        dws, dbs = launcher(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
     return ([cw.out(s, dws[s]) if need_w[s] else None for s in range(nseg)],
             [cb.out(s, dbs[s]) if need_b[s] else None for s in range(nseg)])
 
@@ -438,3 +440,197 @@ class KLDivFn(torch.autograd.Function):
     def backward(ctx, grad_loss):
         scores, target, lse, tsum = ctx.saved_tensors
         return ops.kl_bwd(grad_loss, scores, target, lse, tsum, ctx.divisor), None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 TRAINING path (round 5; ops16.py, csrc/gemm_bf16.hip): the same autograd nodes on bfloat16 activations. Parameters,
+# their gradients (arena slices, fp32), LayerNorm statistics and the softmax statistics stay fp32. What the reference does
+# with `model.half()` + apex FP16_Optimizer (train_concap.py:443-461,504-505), without loss scaling (bf16 keeps fp32's
+# exponent range).
+# ---------------------------------------------------------------------------------------------------------------
+from . import ops16  # noqa: E402
+
+
+class CastFn(Function):
+    """fp32 <-> bfloat16 at the edges of the bf16 stream (embeddings in, sequence outputs out); backward = the other cast."""
+
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        ctx.to_bf16 = to_bf16
+        return ops16.cast_bf16(x) if to_bf16 else ops16.cast_f32(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (ops16.cast_f32(dy) if ctx.to_bf16 else ops16.cast_bf16(dy)), None
+
+
+def _dropped16(dy, drop):
+    tag = getattr(dy, "_vb_dropped", None)
+    if (tag is not None and tag[0] == drop[0] and tag[1] == drop[1] and tag[2].shape == dy.shape
+            and tag[3] == dy.data_ptr() and tag[4] == dy._version):
+        return tag[2]
+    return ops16.dropout(dy, drop[0], drop[1])
+
+
+class Linear16Fn(Function):
+    """y = dropout(x @ cat(W).T + cat(b), p) (+ residual) on bf16 tensors (y fp32 when out_f32: the image-feature projection
+    in front of the fp32 embedding kernel). Inputs: x, residual, nseg, drop_p, out_f32, W..., b... (a linear with an
+    activation of its own is not an autograd node of this path: the FFN is FFN16Fn, functional.linear sends the rest
+    through the fp32 node)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, nseg, drop_p, out_f32, *wb):
+        weights, biases = list(wb[:nseg]), list(wb[nseg:])
+        seed = next_seed() if drop_p > 0.0 else 0
+        y, _ = ops16.linear_fwd(x, weights, biases, None, residual, drop_p=drop_p, seed=seed, out_f32=out_f32)
+        ctx.save_for_backward(x, *weights, *[b for b in biases if b is not None])
+        ctx.nseg = nseg
+        ctx.drop = (drop_p, seed)
+        ctx.has_bias = [b is not None for b in biases]
+        return _tag_drop(y, drop_p, seed) if residual is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x = ctx.saved_tensors[0]
+        nseg = ctx.nseg
+        weights = list(ctx.saved_tensors[1:1 + nseg])
+        rest = list(ctx.saved_tensors[1 + nseg:])
+        biases = [rest.pop(0) if h else None for h in ctx.has_bias]
+        K = weights[0].shape[1]
+        dy = dy.contiguous()
+        if dy.dtype != ops16.BF16:          # fp32 output: the gradient arrives in fp32
+            dy = ops16.cast_bf16(dy)
+        dres = dy if ctx.needs_input_grad[1] else None
+        if ctx.drop[0] > 0.0:
+            dy = _dropped16(dy, ctx.drop)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops16.linear_bwd_input(dy, weights, biases, K).view(x.shape)
+        need_w = [bool(ctx.needs_input_grad[5 + s]) for s in range(nseg)]
+        need_b = [ctx.has_bias[s] and ctx.needs_input_grad[5 + nseg + s] for s in range(nseg)]
+        dws, dbs = [None] * nseg, [None] * nseg
+        if any(need_w) or any(need_b):
+            dws, dbs = _wgrad(dy, x, weights, biases, need_w, need_b, launcher=ops16.linear_bwd_weight)
+        return (dx, dres, None, None, None) + tuple(dws) + tuple(dbs)
+
+
+class FFN16Fn(Function):
+    """y = dropout(gelu(x @ W1.T + b1) @ W2.T + b2, p) + x on bf16 tensors - FFNFn's structure: the up-projection's epilogue
+    stores gelu'(pre) next to the activation, the dgrad through W2 multiplies by it, the dgrad through W1 adds the skip
+    gradient; no elementwise pass over [M, intermediate] in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop_p):
+        seed = next_seed() if drop_p > 0.0 else 0
+        h, dact = ops16.linear_fwd(x, [w1], [b1], "gelu", want_act_grad=True)
+        y, _ = ops16.linear_fwd(h, [w2], [b2], None, x, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x, dact, h, w1, w2, *[b for b in (b1, b2) if b is not None])
+        ctx.drop = (drop_p, seed)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return _tag_drop(y, drop_p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, dact, h, w1, w2 = ctx.saved_tensors[:5]
+        rest = list(ctx.saved_tensors[5:])
+        b1 = rest.pop(0) if ctx.has_bias[0] else None
+        b2 = rest.pop(0) if ctx.has_bias[1] else None
+        dy = dy.contiguous()
+        dyd = _dropped16(dy, ctx.drop) if ctx.drop[0] > 0.0 else dy
+        inter, hidden = w1.shape[0], w1.shape[1]
+        dpre = ops16.linear_bwd_input(dyd, [w2], [b2], inter, mul=dact)
+        dw2 = db2 = dw1 = db1 = dx = None
+        nb2 = bool(ctx.has_bias[1] and ctx.needs_input_grad[4])
+        if ctx.needs_input_grad[3] or nb2:
+            (dw2,), (db2,) = _wgrad(dyd, h, [w2], [b2], [bool(ctx.needs_input_grad[3])], [nb2], launcher=ops16.linear_bwd_weight)
+        if ctx.needs_input_grad[0]:
+            dx = ops16.linear_bwd_input(dpre, [w1], [b1], hidden, residual=dy).view(x.shape)
+        nb1 = bool(ctx.has_bias[0] and ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[1] or nb1:
+            (dw1,), (db1,) = _wgrad(dpre, x, [w1], [b1], [bool(ctx.needs_input_grad[1])], [nb1], launcher=ops16.linear_bwd_weight)
+        return dx, dw1, db1, dw2, db2, None
+
+
+class LayerNorm16Fn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops16.layernorm_fwd(x, gamma, beta, eps, want_stats=True)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.drop_hint = getattr(x, "_vb_drop", None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        c = _Claims([gamma, beta], [need_g, need_b])
+        res = ops16.layernorm_bwd(dy, x, mean, rstd, gamma, c.fresh_or_none(0), c.fresh_or_none(1), drop=ctx.drop_hint)
+        dx, dgamma, dbeta = res[:3]
+        out = dx.view(x.shape)
+        if len(res) == 4:
+            out._vb_dropped = (ctx.drop_hint[0], ctx.drop_hint[1], res[3].view(x.shape), out.data_ptr(), out._version)
+        return (out, (c.finish_overwrite(0, dgamma) if need_g else None), (c.finish_overwrite(1, dbeta) if need_b else None),
+                None)
+
+
+class SelfAttn16Fn(Function):
+    """Attention over one fused bf16 [q | k | v] projection; context and dqkv bf16, softmax statistics fp32."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask_add, heads, drop_p):
+        H = qkv.shape[-1] // 3
+        seed = next_seed() if drop_p > 0.0 else 0
+        out, lse = ops16.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads, True, drop_p, seed)
+        ctx.save_for_backward(qkv, mask_add, lse)
+        ctx.meta = (heads, drop_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, mask_add, lse = ctx.saved_tensors
+        heads, drop_p, seed = ctx.meta
+        H = qkv.shape[-1] // 3
+        dqkv = torch.empty_like(qkv)
+        ops16.attention_bwd(d_out, qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads, lse,
+                            dqkv[..., :H], dqkv[..., H:2 * H], dqkv[..., 2 * H:], drop_p, seed)
+        return dqkv, None, None, None
+
+
+class BiAttn16Fn(Function):
+    """Both directions of the co-attention on the two fused bf16 projections (BiAttnFn's structure)."""
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, mask1, mask2, heads, p1, p2):
+        H = qkv1.shape[-1] // 3
+        s1 = next_seed() if p1 > 0.0 else 0
+        s2 = next_seed() if p2 > 0.0 else 0
+        sl = lambda t: (t[..., :H], t[..., H:2 * H], t[..., 2 * H:])
+        q1, k1, v1 = sl(qkv1)
+        q2, k2, v2 = sl(qkv2)
+        ctx1, lse1 = ops16.attention_fwd(q2, k1, v1, mask1, heads, True, p1, s1)
+        ctx2, lse2 = ops16.attention_fwd(q1, k2, v2, mask2, heads, True, p2, s2)
+        ctx.save_for_backward(qkv1, qkv2, mask1, mask2, lse1, lse2)
+        ctx.meta = (heads, p1, p2, s1, s2)
+        ctx.set_materialize_grads(False)
+        return ctx1, ctx2
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        qkv1, qkv2, mask1, mask2, lse1, lse2 = ctx.saved_tensors
+        heads, p1, p2, s1, s2 = ctx.meta
+        if d1 is None and d2 is None:
+            return (None,) * 7
+        H = qkv1.shape[-1] // 3
+        if d1 is None:
+            d1 = torch.zeros((max(qkv1.shape[0], qkv2.shape[0]), qkv2.shape[1], H), dtype=qkv1.dtype, device=qkv1.device)
+        if d2 is None:
+            d2 = torch.zeros((max(qkv1.shape[0], qkv2.shape[0]), qkv1.shape[1], H), dtype=qkv1.dtype, device=qkv1.device)
+        sl = lambda t: (t[..., :H], t[..., H:2 * H], t[..., 2 * H:])
+        q1, k1, v1 = sl(qkv1)
+        q2, k2, v2 = sl(qkv2)
+        dqkv1, dqkv2 = torch.empty_like(qkv1), torch.empty_like(qkv2)
+        dq1, dk1, dv1 = sl(dqkv1)
+        dq2, dk2, dv2 = sl(dqkv2)
+        ops16.attention_bwd(d1, q2, k1, v1, mask1, heads, lse1, dq2, dk1, dv1, p1, s1)
+        ops16.attention_bwd(d2, q1, k2, v2, mask2, heads, lse2, dq1, dk2, dv2, p2, s2)
+        return dqkv1, dqkv2, None, None, None, None, None

@@ -24,6 +24,7 @@ from torch import nn
 from torch.nn import CrossEntropyLoss
 import torch.nn.functional as TF
 
+from . import _native
 from . import functional as F
 from . import ops
 from .utils import PreTrainedModel
@@ -235,7 +236,10 @@ def _self_attention(mod, hidden_states, attention_mask, gates=None):
     H = mod.all_head_size
     # MX inference mode: the projection leaves its GEMM as bf16 and the attention kernel returns the context as MX codes
     S = hidden_states.shape[1] if hidden_states.dim() == 3 else 10 ** 9
-    to_mx = ops.mx_attention_ok(S, S, mod.attention_head_size, _drop_p(mod.dropout), mod.visualization or gates is not None)
+    # (decided for the whole block: the consuming output projection must be able to take an MX context - in train mode
+    # under no_grad its hidden dropout makes it ineligible)
+    to_mx = not mod.training and ops.mx_attention_ok(S, S, mod.attention_head_size, _drop_p(mod.dropout),
+                                                     mod.visualization or gates is not None)
     qkv = F.linear(hidden_states, [mod.query.weight, mod.key.weight, mod.value.weight],
                    [mod.query.bias, mod.key.bias, mod.value.bias], out="bf16" if to_mx else "f32")
     if gates is not None:  # dynamic_attention (:577-586): rare path, small elementwise gates kept in torch
@@ -278,7 +282,7 @@ def _dense_dropout_add_norm(dense, dropout, norm, hidden_states, input_tensor):
     (training and eval), followed by one LayerNorm pass."""
     # (MX inference mode: the sum leaves the GEMM as bf16 and the LayerNorm keeps the residual stream in bf16)
     return norm(F.linear(hidden_states, dense.weight, dense.bias, residual=input_tensor, drop_p=_drop_p(dropout),
-                         out="bf16" if ops.mx_stream_bf16() else "f32"))
+                         out="bf16" if ops.mx_stream_bf16() and not dense.training else "f32"))
 
 
 def _ffn(intermediate, output, x):
@@ -464,7 +468,7 @@ class BertBiAttention(nn.Module):
                 use_co_attention_mask=False):
         H = self.all_head_size
         S1, S2 = input_tensor1.shape[1], input_tensor2.shape[1]
-        to_mx = (ops.mx_attention_ok(max(S1, S2), max(S1, S2), self.attention_head_size,
+        to_mx = (not self.training and ops.mx_attention_ok(max(S1, S2), max(S1, S2), self.attention_head_size,
                                      max(_drop_p(self.dropout1), _drop_p(self.dropout2)), self.visualization)
                  and all(ops.mx_eligible(w.shape[1], 3 * w.shape[0]) for w in (self.query1.weight, self.query2.weight)))
         fmt = "bf16" if to_mx else "f32"
@@ -574,13 +578,20 @@ class BertEncoder(nn.Module):
         use_co_attention_mask = False
         dynamic = len(self.v_layer) > 0 and self.v_layer[0].attention.self.dynamic_attention
 
+        def thaw(x, frozen):
+            # a frozen prefix runs under no_grad: in the MX inference mode it may hand over a bf16 hidden state, which
+            # the grad-enabled layers behind it (fp32 kernels unless the bf16 stream is on) cannot take
+            if frozen and torch.is_grad_enabled() and x.dtype == torch.bfloat16 and not _native.bf16_stream():
+                return F.to_f32(x)
+            return x
+
         def run_text(lo, hi, x, frozen=False):
             for idx in range(lo, hi):
                 with torch.set_grad_enabled(torch.is_grad_enabled() and not frozen):
                     x, probs = self.layer[idx](x, txt_attention_mask)
                 if output_all_attention_masks:
                     all_attention_mask_t.append(probs)
-            return x
+            return thaw(x, frozen)
 
         def run_image(lo, hi, x, frozen=False):
             for idx in range(lo, hi):
@@ -588,7 +599,7 @@ class BertEncoder(nn.Module):
                     x, probs = self.v_layer[idx](x, image_attention_mask, txt_embedding, txt_attention_mask2)
                 if output_all_attention_masks:
                     all_attnetion_mask_v.append(probs)
-            return x
+            return thaw(x, frozen)
 
         for v_end, t_end in zip(self.v_biattention_id, self.t_biattention_id):
             assert self.fixed_t_layer <= t_end
@@ -833,7 +844,12 @@ class BertImageEmbeddings(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, input_ids, input_loc):
-        proj = F.linear(input_ids.float(), self.image_embeddings.weight, self.image_embeddings.bias)
+        if _native.bf16_stream() and input_ids.is_cuda:
+            # bf16 mode: the [regions x 2048] features are rounded to bf16 once (they need no gradient), the projection
+            # runs on the bf16 GEMM with an fp32 result for the (fp32) location + sum + LayerNorm row kernel
+            proj = F.linear_f32_out(F.to_bf16(input_ids.float()), self.image_embeddings.weight, self.image_embeddings.bias)
+        else:
+            proj = F.linear(input_ids.float(), self.image_embeddings.weight, self.image_embeddings.bias)
         out = F.image_embed_ln(proj, input_loc.float(), self.image_location_embeddings.weight,
                                self.image_location_embeddings.bias, self.LayerNorm.weight, self.LayerNorm.bias,
                                self.LayerNorm.variance_epsilon)
@@ -887,15 +903,20 @@ class BertModel(BertPreTrainedModel):
 
         embedding_output = self.embeddings(input_txt, token_type_ids, task_ids)
         v_embedding_output = self.v_embeddings(input_imgs, image_loc)
+        if _native.bf16_stream() and embedding_output.is_cuda and not self.config.dynamic_attention:
+            # bf16 mode (round 5): the two hidden-state streams enter the encoder as bfloat16 and stay bfloat16 - activations,
+            # saved tensors and their gradients - until the casts below (functional.py dispatches on the dtype)
+            embedding_output, v_embedding_output = F.to_bf16(embedding_output), F.to_bf16(v_embedding_output)
         encoded_layers_t, encoded_layers_v, all_attention_mask = self.encoder(
             embedding_output, v_embedding_output, extended_attention_mask, extended_attention_mask2,
             extended_image_attention_mask, extended_co_attention_mask,
             output_all_encoded_layers=output_all_encoded_layers,
             output_all_attention_masks=output_all_attention_masks)
 
-        # MX inference mode: the encoder keeps its residual stream in bf16; the callers (poolers, heads, users) get fp32
-        encoded_layers_t = [t.float() if t.dtype == torch.bfloat16 else t for t in encoded_layers_t]
-        encoded_layers_v = [t.float() if t.dtype == torch.bfloat16 else t for t in encoded_layers_v]
+        # bf16 mode / MX inference mode: the encoder keeps its residual stream in bf16; the callers (poolers, heads, users)
+        # get fp32
+        encoded_layers_t = [F.to_f32(t) for t in encoded_layers_t]
+        encoded_layers_v = [F.to_f32(t) for t in encoded_layers_v]
         sequence_output_t, sequence_output_v = encoded_layers_t[-1], encoded_layers_v[-1]
         pooled_output_t = self.t_pooler(sequence_output_t)
         pooled_output_v = self.v_pooler(sequence_output_v)
@@ -916,7 +937,10 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         self.num_negative = config.num_negative
         # None: the labelled rows are gathered exactly (one host sync per step); a fraction in (0, 1]: sync-free
         # fixed-capacity gather of that share of the token / region positions (see _losses_at_labelled_positions)
+        # None: exact gather of the labelled rows (one host sync per step); a fraction of the positions or "auto": sync-free
+        # fixed-capacity gather (see _losses_at_labelled_positions)
         self.label_capacity = None
+        self._auto_capacity = None
         self._label_counts = None
         self._label_overflow = None     # device flag: a fixed-capacity label gather dropped rows (sticky until checked)
         self.loss_fct = CrossEntropyLoss(ignore_index=-1)
@@ -984,6 +1008,13 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
         n_reg_all = sequence_output_v.size(1)                       # regions incl. the global row 0
         per = n_reg_all - 1
         static = (self.label_capacity is not None or torch.cuda.is_current_stream_capturing()) and self.visual_target == 0
+        if static and self.label_capacity == "auto" and self._auto_capacity is None and not torch.cuda.is_current_stream_capturing():
+            # "auto": the FIRST step counts its labelled rows on the host (one sync, the exact path below) and fixes the gather
+            # capacity at 1.2 x the larger of the two labelled fractions (+ 1 % of the positions); every later step is
+            # sync-free. check_label_capacity() - every k steps, off the hot path - raises if a batch ever exceeds it.
+            frac = max(float((lm_flat != -1).sum()) / max(lm_flat.numel(), 1), float(labelled.sum()) / max(labelled.numel(), 1))
+            self._auto_capacity = min(1.0, 1.2 * frac + 0.01)
+            static = False
         if static:
             # Sync-free variant (HIP-graph capture, small per-GPU batches): the labelled rows are gathered into
             # FIXED-capacity buffers (torch.nonzero_static), the host never learns the counts. Padding rows carry
@@ -991,6 +1022,8 @@ class BertForMultiModalPreTraining(BertPreTrainedModel):
             # divisors are device scalars. Counts above the capacity would silently drop rows, so they are recorded
             # for check_label_capacity() (GraphedTrainStep polls it without stalling the device).
             frac = self.label_capacity if self.label_capacity is not None else 0.25
+            if frac == "auto":
+                frac = self._auto_capacity if self._auto_capacity is not None else 0.25
             cap_t = _capacity(lm_flat.numel(), frac)
             cap_r = _capacity(labelled.numel(), frac)
             mask_t = lm_flat != -1
