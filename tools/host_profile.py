@@ -37,6 +37,8 @@ def main():
              "image_attention_mask", "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
     inp = tuple(xb[n].to(device) for n in names)
     net = bench.build_model(cfg, "pretraining", device).train()
+    if os.environ.get("VB_LABEL_GATHER", "auto") == "auto":
+        net.label_capacity = "auto"       # sync-free gather of the labelled rows (what bench.py times by default since round 5)
     opt = AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.98), weight_decay=0.01)
 
     def step():

@@ -48,11 +48,30 @@ __device__ __forceinline__ void st1(io_t* p, float v) {
     const unsigned u = __float_as_uint(v);
     *p = (io_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+// one output row piece: element a[dt][r] belongs to column 16 dt + c of the row; `op` already points at column c. Lanes c and
+// c ^ 1 trade one value per pair of 16-column blocks, so that every lane stores TWO adjacent bf16 columns (4 bytes) per pair
+// instead of one 2-byte element per block: half the store instructions (these kernels' tails are store-issue-bound).
+template <int DS>
+__device__ __forceinline__ void store_cols(io_t* op, int c, const f32x4 (&a)[DS], int r) {
+    auto bf = [](float v) -> unsigned { const unsigned u = __float_as_uint(v); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+#pragma unroll
+    for (int k = 0; k < DS / 2; ++k) {
+        const float even = a[2 * k][r], odd = a[2 * k + 1][r];
+        const float recv = __shfl_xor((c & 1) ? even : odd, 1, 64);
+        if (c & 1) *reinterpret_cast<unsigned*>(op + 32 * k + 15) = bf(recv) | (bf(odd) << 16);     // columns 32 k + 16 + c - 1, + c
+        else *reinterpret_cast<unsigned*>(op + 32 * k) = bf(even) | (bf(recv) << 16);               // columns 32 k + c, + c + 1
+    }
+}
 #else
 typedef float io_t;
 __device__ __forceinline__ f32x4 ld4(const io_t* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ float ld1(const io_t* p) { return *p; }
 __device__ __forceinline__ void st1(io_t* p, float v) { *p = v; }
+template <int DS>
+__device__ __forceinline__ void store_cols(io_t* op, int c, const f32x4 (&a)[DS], int r) {
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt) op[16 * dt] = a[dt][r];
+}
 #endif
 
 struct AttnP {
@@ -265,8 +284,7 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
         const int q = qt * 16 + 4 * g + r;
         if (q < p.n_q) {
             io_t* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
-#pragma unroll
-            for (int dt = 0; dt < DS; ++dt) st1(op + 16 * dt, oacc[dt][r]);
+            store_cols<DS>(op, c, oacc, r);
         }
     }
 }
@@ -361,11 +379,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
         if (kk < p.n_k) {
             io_t* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
             io_t* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
-#pragma unroll
-            for (int dt = 0; dt < DS; ++dt) {
-                st1(kp + 16 * dt, dk[dt][r]);
-                st1(vp + 16 * dt, dv[dt][r]);
-            }
+            store_cols<DS>(kp, c, dk, r);
+            store_cols<DS>(vp, c, dv, r);
         }
     }
 }
@@ -572,8 +587,7 @@ __global__ __launch_bounds__(256, 3) void attn_q_lds_kernel(const AttnP p_in) { 
             const int q = qt * 16 + 4 * g + r;
             if (q < p.n_q) {
                 io_t* op = obase + ((long)b * p.n_q + q) * ldo + h * D + c;
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt) st1(op + 16 * dt, oacc[dt][r]);
+                store_cols<DS>(op, c, oacc, r);
             }
         }
     }
@@ -662,11 +676,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
             if (kk < p.n_k) {
                 io_t* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
                 io_t* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt) {
-                    st1(kp + 16 * dt, dk[dt][r]);
-                    st1(vp + 16 * dt, dv[dt][r]);
-                }
+                store_cols<DS>(kp, c, dk, r);
+                store_cols<DS>(vp, c, dv, r);
             }
         }
     }
@@ -821,8 +832,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
             const int q = qt * 16 + 4 * g + r;
             if (q < p.n_q) {
                 io_t* op = p.dQ + ((long)b * p.n_q + q) * p.lddq + h * D + c;
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt) st1(op + 16 * dt, oacc[dt][r]);
+                store_cols<DS>(op, c, oacc, r);
             }
         }
     }
@@ -877,11 +887,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
             if (kk < p.n_k) {
                 io_t* kp = p.dK + ((long)b * p.n_k + kk) * p.lddk + h * D + c;
                 io_t* vp = p.dV + ((long)b * p.n_k + kk) * p.lddv + h * D + c;
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt) {
-                    st1(kp + 16 * dt, dk[dt][r]);
-                    st1(vp + 16 * dt, dv[dt][r]);
-                }
+                store_cols<DS>(kp, c, dk, r);
+                store_cols<DS>(vp, c, dv, r);
             }
         }
     }

@@ -398,7 +398,19 @@ struct HwP {
     int flags;                      // laboratory (VB_BF16_FLAGS), as HbP
 };
 
-__device__ __forceinline__ void hw_unit(const HwP& p, int u, int& n0, int& k0, int& kt0, int& nk) {
+// unit of block `b` in its i-th round: the 32 blocks of an XCD (b % 8) take CONSECUTIVE units - the same contraction split and
+// neighbouring output tiles - so that the row range of dY / X they stream is shared in their L2 (hb_tile_of's map)
+// (grid = a multiple of 8; any unit count: XCD x takes the units [x per, (x + 1) per) of the round, per = ceil(n / 8))
+__device__ __forceinline__ int hw_unit_of(int b, int i, int grid, int units) {
+    const int base = i * grid;
+    const int n = min(grid, units - base);
+    if (n <= 0) return -1;
+    const int per = (n + 7) >> 3, x = b & 7, j = b >> 3;
+    const int idx = x * per + j;
+    return (j < per && idx < n) ? base + idx : -1;
+}
+__device__ __forceinline__ void hw_unit(const HwP& p, int b, int i, int grid, int& n0, int& k0, int& kt0, int& nk) {
+    const int u = hw_unit_of(b, i, grid, p.units);
     const int split = u / p.tiles, t = u - split * p.tiles;
     n0 = (t / p.tiles_k) * HB_BM;
     k0 = (t % p.tiles_k) * HB_BN;
@@ -426,12 +438,12 @@ __device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, con
     long total = 0;
     for (int i = 0; i < n_units; ++i) {
         int n0, k0, a, c;
-        hw_unit(p, blockIdx.x + i * gridDim.x, n0, k0, a, c);
+        hw_unit(p, blockIdx.x, i, gridDim.x, n0, k0, a, c);
         total += c;
     }
     auto set_unit = [&](int i) {
         int n0, k0;
-        hw_unit(p, blockIdx.x + i * gridDim.x, n0, k0, kt0, nk);
+        hw_unit(p, blockIdx.x, i, gridDim.x, n0, k0, kt0, nk);
         base = mat + (long)kt0 * HB_BK * ld + (IS_A ? n0 : k0);
         kt = 0;
     };
@@ -474,8 +486,9 @@ __device__ __forceinline__ void hw_loader(const HwP& p, const unsigned lds0, con
 __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, grid = gridDim.x;
-    const int n_units = (p.units - b + grid - 1) / grid;
-    if (n_units <= 0) return;
+    int n_units = 0;
+    while (n_units * grid < p.units && hw_unit_of(b, n_units, grid, p.units) >= 0) ++n_units;
+    if (n_units == 0) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= HB_MFMA_WAVES) {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
     int st = 0;
     for (int ui = 0; ui < n_units; ++ui) {
         int n0, k0, kt0, nk;
-        hw_unit(p, b + ui * grid, n0, k0, kt0, nk);
+        hw_unit(p, b, ui, grid, n0, k0, kt0, nk);
         const bool do_bias = k0 == 0 && wn == 0 && p.bias[n0 / p.cseg] != nullptr;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -851,13 +864,22 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     p.tiles_k = p.K / HB_BN;
     p.tiles = (p.N / HB_BM) * p.tiles_k;
     p.nkt = (p.M + HB_BK - 1) / HB_BK;
-    // units of ~24 or more contraction tiles, a whole number of rounds of the 256 persistent blocks where the sizes allow
-    const long work = (long)p.tiles * p.nkt;
-    const int rounds = (int)((work + 256 * 24 / 2) / (256 * 24)) > 0 ? (int)((work + 256 * 24 / 2) / (256 * 24)) : 1;
-    int splits = (256 * rounds) / p.tiles;
-    if (splits < 1) splits = 1;
-    if (splits > p.nkt) splits = p.nkt;
-    p.kt_per_split = (p.nkt + splits - 1) / splits;
+    // Contraction splits by a time model (measured with the laboratory flags, profiles/r05_bf16_lab_ablations.txt): a unit's
+    // main loop costs ~1.0 us per contraction tile, its epilogue - 128 KiB of fp32 atomics that execute at the memory side,
+    // ~1.7 TB/s for the whole chip - ~0.075 us per unit IN FLIGHT ANYWHERE; rounds of 256 units. More splits shorten the main
+    // loop and lengthen the atomics: the first version's "fill two rounds" rule spent 30 - 50 % of a launch in atomics.
+    static const float t_k = [] { const char* e = getenv("VB_BF16_WG_TK"); return e ? (float)atof(e) : 1.0f; }();
+    static const float t_e = [] { const char* e = getenv("VB_BF16_WG_TE"); return e ? (float)atof(e) : 0.075f; }();
+    int best = 1;
+    float best_t = 1e30f;
+    for (int sp = 1; sp <= p.nkt && sp <= 64; ++sp) {
+        const int per = (p.nkt + sp - 1) / sp, real = (p.nkt + per - 1) / per;
+        if (real != sp) continue;
+        const long units = (long)p.tiles * sp;
+        const float t = (float)((units + 255) / 256) * (per * t_k + 2.0f) + units * t_e;
+        if (t < best_t) { best_t = t; best = sp; }
+    }
+    p.kt_per_split = (p.nkt + best - 1) / best;
     p.splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
     p.units = p.tiles * p.splits;
     static const int lab_flags = [] { const char* e = getenv("VB_BF16_FLAGS"); return e ? atoi(e) : 0; }();
@@ -865,7 +887,7 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
     if (attr != hipSuccess) return (int)attr;
-    const int grid = p.units < 256 ? p.units : 256;
+    const int grid = p.units < 256 ? (p.units + 7) / 8 * 8 : 256;
     hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(grid), dim3(HB_THREADS), HB_LDS, static_cast<hipStream_t>(stream), p);
     VB_LAUNCH_CHECK();
     return 0;

@@ -17,6 +17,10 @@ __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
     return f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
                  __uint_as_float(w.y & 0xffff0000u)};
 }
+__device__ __forceinline__ f32x4 unpack4(const uint2 w) {
+    return f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                 __uint_as_float(w.y & 0xffff0000u)};
+}
 __device__ __forceinline__ void store4(unsigned short* p, const f32x4 v) {
     *reinterpret_cast<uint2*>(p) = uint2{(unsigned)bf16_rne(v[0]) | ((unsigned)bf16_rne(v[1]) << 16),
                                          (unsigned)bf16_rne(v[2]) | ((unsigned)bf16_rne(v[3]) << 16)};
@@ -158,10 +162,18 @@ __global__ __launch_bounds__(1024) void ln16_colreduce_kernel(long parts, int wi
     __shared__ float red[16][65];
     const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (col < width)
-        for (long p = r; p < parts; p += 16) s += ws[p * width + col];
-    red[r][c] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < width) {
+        long p = r;
+        for (; p + 48 < parts; p += 64) {          // four loads in flight per thread
+            s0 += ws[p * width + col];
+            s1 += ws[(p + 16) * width + col];
+            s2 += ws[(p + 32) * width + col];
+            s3 += ws[(p + 48) * width + col];
+        }
+        for (; p < parts; p += 16) s0 += ws[p * width + col];
+    }
+    red[r][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (r == 0 && col < width) {
         float t = 0.f;
