@@ -32,6 +32,14 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+BF16_DTYPE = "bf16 activations / saved tensors / activation gradients in HBM, bf16 MFMA operands, fp32 accumulate; fp32 master " \
+             "weights, weight gradients, LayerNorm and softmax statistics, AdamW - NOT inside the 1e-4 parity bar " \
+             "(tests/test_bf16_stream_gpu.py: its measured errors)"
+BF16_NOTE = "opt-in reduced-precision TRAINING mode (round 5; the reference's model.half() + FP16_Optimizer, train_concap.py:443-461): " \
+            "the encoder's hidden states, saved tensors and their gradients are bfloat16 tensors (vilbert/ops16.py, " \
+            "csrc/gemm_bf16.hip), fp32 master weights with bf16 shadows refreshed once per step, fp32 weight gradients in the " \
+            "arena; outside the 1e-4 parity bar (loss within 2e-2, gradient error median 3.5e-2: tests/test_bf16_stream_gpu.py, " \
+            "test_gemm_modes_gpu.py); bf16 dense MFMA peak 2500 TF"
 CONFIG = "bert_base_6layer_6conect.json"
 N_TOK, N_REG = 36, 36
 PEAK_FP32_MFMA_TFLOPS = 157.3  # gfx950 v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
@@ -333,7 +341,8 @@ def main():
             net = build_model(cfg, "pretraining", device).train()
             if world > 1 or args.force_ddp:
                 from vilbert.distributed import DistributedDataParallel
-                net = DistributedDataParallel(net, algorithm=args.ddp_algorithm)
+                net = DistributedDataParallel(net, algorithm=args.ddp_algorithm,
+                                              direct_at_world_size_one=args.force_ddp and args.ddp_algorithm == "direct")
             decay = [p for n, p in net.named_parameters() if p.requires_grad and not any(
                 k in n for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
             no_decay = [p for n, p in net.named_parameters() if p.requires_grad and any(
@@ -378,6 +387,15 @@ def main():
             _vb2.set_two_streams(two_)
             _ao2.set_wgrad_stream(ws_)
         return (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), n
+
+    def bf16_roofline(tf, n):
+        return {"bound": "mfma", "kernel": "gemm_bf16_kernel (forward + dgrad through the transposed weight shadow) + "
+                "wgrad_bf16_kernel (ds_read_b64_tr_b16 fragments), v_mfma_f32_32x32x16_bf16, persistent 256x128 tiles: 8 MFMA + 4 "
+                "LDS-DMA loader waves per CU; the heads / poolers on gemm_planes_kernel (fp32 tensors, bf16 operands)",
+                "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                "launches_per_step": n, "traffic": None,
+                "what": "all GEMM launches of one extra step (fwd + dgrad + wgrad), algorithmic 2MNK FLOPs / sum of HIP-event "
+                        "durations (single stream); bf16 dense MFMA peak 2500 TF"}
 
     def comm_model(step64_ms):
         """What the gradient exchange will cost at N = 8, from what CAN be measured on one GPU: the real bucket layout
@@ -547,6 +565,14 @@ def main():
         return dt
 
     elapsed = timed(step, args.warmup, args.steps)
+    label_gather_info = None
+    if args.mode == "train":
+        bm = train_state.get("model")
+        bm = bm.module if hasattr(bm, "module") else bm
+        cap = getattr(bm, "_auto_capacity", None)
+        label_gather_info = "exact (torch.nonzero, one host sync per step)" if args.label_gather == "exact" or cap is None else \
+            "fixed capacity %.3f of the positions (1.2 x the first step's labelled fraction + 0.01), no host sync per step; " \
+            "overflow checked after every timed region" % cap
 
     # Roofline of the dominant kernel (the fp32-MFMA GEMM family, ~99 % of the FLOPs): every
     # vb_linear_fwd launch of extra profiled steps is bracketed with HIP events on the launch stream.
@@ -580,9 +606,7 @@ def main():
         alt = {}
         notes = {"bf16x6": "opt-in (--gemm-mode bf16x6 / VB_GEMM_MODE): fp32 operands split into 3 bf16 planes, 6 MFMA "
                            "products, fp32-class result - the same parity tests pass; GEMM ceiling 2500/6 = 417 TF",
-                 "bf16": "opt-in reduced-precision mode (BASELINE configs[4] direction): operands rounded to bf16, one "
-                         "MFMA product, fp32 accumulate, fp32 tensors in HBM; NOT inside the 1e-4 parity bar (measured "
-                         "error ~1e-2 of the output range, tests/test_gemm_modes_gpu.py); bf16 MFMA peak 2500 TF"}
+                 "bf16": BF16_NOTE}
         notes["fp8"] = "opt-in: FORWARD linears on OCP e4m3 operands (csrc/fp8.hip), backward GEMMs exact fp32 on the saved " \
                        "fp32 activations (straight-through); outside the 1e-4 parity bar (tests/test_fp8_gpu.py)"
         notes["fp8+bf16"] = "opt-in: fp8 forward linears (as 'fp8') + bf16-operand backward GEMMs (as 'bf16'), fp32 master " \
@@ -593,17 +617,28 @@ def main():
         #  tests/test_gemm_modes_gpu.py::test_reduced_precision_training_modes_report_their_gradient_error)
         for mode in ("bf16x6", "bf16", "fp8+bf16"):
             _native.set_gemm_mode(mode)
-            for _ in range(2):
+            for _ in range(3):
                 step()
             torch.cuda.synchronize()
             ta = time.perf_counter()
-            alt_steps = max(3, args.steps // 2)
+            alt_steps = max(10, args.steps) if mode == "bf16" else max(3, args.steps // 2)
             for _ in range(alt_steps):
                 step()
             torch.cuda.synchronize()
             alt_ms = 1e3 * (time.perf_counter() - ta) / alt_steps
             alt[mode] = {"value": round(B / (alt_ms * 1e-3), 2), "unit": "samples/s", "ms_per_step": round(alt_ms, 3),
                          "steps": alt_steps, "note": notes[mode]}
+            if mode == "bf16":
+                # its own roofline object: every GEMM launch of one more (single-stream) step under HIP events, against the
+                # dense bf16 MFMA peak
+                tf16, n16 = gemm_family_tf(step)
+                alt[mode]["dtype"] = BF16_DTYPE
+                alt[mode]["roofline"] = bf16_roofline(tf16, n16)
+                b64_16, _, _ = train_workload(64)
+                d64 = timed(b64_16, 3, 10)
+                alt[mode]["b64"] = {"value": round(64 * 10 / d64, 2), "unit": "samples/s", "ms_per_step": round(1e3 * d64 / 10, 3),
+                                    "steps": 10, "note": "the same mode at the reference's per-GPU batch 64 (global 512 over 8 GPUs)"}
+                del b64_16
         _native.set_gemm_mode("f32")
 
     # PCIe-inclusive leg (opt-in): raw worker-shaped numpy batches on the host -> pinned staging -> async H2D on
@@ -674,7 +709,7 @@ def main():
                     "reduce_scatter_tensor + all_gather_into_tensor in place on the arena range (vilbert/distributed.py)"}
     if default_line and 512 % world == 0:
         gstep, gx, _ = train_workload(512 // world)
-        n_g = max(3, args.steps // 2)
+        n_g = max(10, args.steps)
         g_dt = timed(gstep, 2, n_g)
         extra["global512"] = {"value": round(512 * n_g / g_dt, 2), "unit": "samples/s", "global_batch": 512,
                               "per_gpu_batch": 512 // world, "ms_per_step": round(1e3 * g_dt / n_g, 3), "steps": n_g,
@@ -746,8 +781,10 @@ def main():
                                        "note": "BASELINE configs[4]: forward with every nn.Linear whose K and N are multiples of "
                                                "128 on MX e4m3 operands (one E8M0 scale per 32 K elements, applied by "
                                                "v_mfma_scale_f32_32x32x64_f8f6f4), codes emitted by LayerNorm / the GELU "
-                                               "epilogue (no quantiser pass, no fp32 FFN activation); attention, LayerNorm "
-                                               "statistics and the residual stream stay fp32; fp8 dense MFMA peak 5000 TF"}
+                                               "epilogue (no quantiser pass, no fp32 FFN activation); residual stream between the layers "
+                                               "in %s, attention on bf16 q | k | v with fp32 softmax and an MX context, LayerNorm "
+                                               "statistics fp32; fp8 dense MFMA peak 5000 TF" % os.environ.get("VB_MX_STREAM", "bf16"),
+                                       "mx_stream": os.environ.get("VB_MX_STREAM", "bf16")}
             # its own roofline object: every MX / fp8 GEMM launch of two more forwards bracketed with HIP events, single stream
             # (as the headline's); bound: the scaled-MFMA peak. Counter-side bytes of the dominant launch: tools/pmc_mx.sh
             two_mx = _vb.set_two_streams(False)
@@ -855,24 +892,25 @@ def main():
         }
         line["config"]["gemm_mode"] = args.gemm_mode
         if args.mode == "train":
-            bm = train_state.get("model")
-            bm = bm.module if hasattr(bm, "module") else bm
-            cap = getattr(bm, "_auto_capacity", None)
-            line["config"]["label_gather"] = "exact (torch.nonzero, one host sync per step)" if args.label_gather == "exact" or cap is None \
-                else "fixed capacity %.3f of the positions (1.2 x the first step's labelled fraction + 0.01), no host sync per step; " \
-                     "overflow checked after every timed region" % cap
+            line["config"]["label_gather"] = label_gather_info
         # the STATE, not the flag: ordered split-K is the default (VB_DETERMINISTIC=0 switches to atomics); fallbacks =
         # split launches that wanted the ordered reduce and ran with atomics (no free workspace slice)
         line["config"]["deterministic_wgrad"] = bool(_native._DET["wanted"]) and _native.deterministic_workspace(device) is not None
         line["config"]["deterministic_fallbacks"] = _native.deterministic_fallbacks()
         line.update(extra)
         if alt:
+            if "bf16" in alt:
+                alt["bf16"]["model_tflops"] = round(alt["bf16"]["value"] * mult * exec_f / 1e12, 1)
+                alt["bf16"]["model_frac_of_bf16_mfma_peak"] = round(alt["bf16"]["model_tflops"] / 2500.0, 4)
             line["alt_gemm_modes"] = alt
         if host_leg is not None:
             line["host_inputs"] = host_leg
         if args.gemm_mode in ("fp8", "mxfp8"):
-            line["dtype"] = "OCP e4m3 operands (row-wise scales), fp32 accumulate, forward linears only - NOT inside the " \
-                            "1e-4 parity bar, see tests/test_fp8_gpu.py for its measured drift"
+            line["dtype"] = "OCP e4m3 operands, fp32 accumulate, forward linears only - NOT inside the 1e-4 parity bar; " + (
+                "one scale per row (csrc/fp8.hip; drift: tests/test_fp8_gpu.py)" if args.gemm_mode == "fp8" else
+                "MX block format: one E8M0 scale per 32 contraction elements applied by the scaled MFMA, bf16 residual stream "
+                "(VB_MX_STREAM=%s), bf16 attention operands with fp32 softmax (csrc/mx8.hip; drift: tests/test_mx_gpu.py, "
+                "test_mx_bench_shapes_gpu.py)" % os.environ.get("VB_MX_STREAM", "bf16"))
             line["roofline"].update(peak=5000.0, frac=round(achieved / 5000.0, 4),
                                     kernel="gemm_fp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4) - meaningful with --mode "
                                            "forward (backward GEMMs stay fp32)",
@@ -880,12 +918,13 @@ def main():
         elif args.gemm_mode != "f32":
             peak = 2500.0 / {"bf16x6": 6, "bf16x3": 3, "bf16": 1}[args.gemm_mode]
             line["dtype"] = "f32 operands split into bf16 planes (%s), fp32 accumulate" % args.gemm_mode
-            if args.gemm_mode == "bf16":
-                line["dtype"] = "bf16 operands (fp32 tensors rounded on the way into LDS), fp32 accumulate - NOT inside " \
-                                "the 1e-4 parity bar, see tests/test_gemm_modes_gpu.py for its measured error"
             line["roofline"].update(peak=round(peak, 1), frac=round(achieved / peak, 4),
                                     kernel="gemm_planes_kernel (v_mfma_f32_32x32x16_bf16, %s)" % args.gemm_mode,
                                     peak_note="bf16 dense MFMA peak 2500 TF / MFMA products per fp32 product")
+            if args.gemm_mode == "bf16":
+                line["dtype"] = BF16_DTYPE
+                line["roofline"].update(bf16_roofline(achieved, gemm_launches // prof_steps))
+                line["roofline"]["traffic_note"] = "not measured for this mode"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.mode)
     if dist.is_initialized():

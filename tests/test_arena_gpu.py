@@ -133,9 +133,9 @@ def test_ddp_world_size_one_with_two_streams_matches_unwrapped(no_dropout):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     prev = V.set_two_streams(True)
     try:
-        def run(wrap):
+        def run(wrap, **kw):
             m = _model(cfg, sd)
-            w = DDP(m, message_size=4 * 1024 * 1024) if wrap else m
+            w = DDP(m, message_size=4 * 1024 * 1024, **kw) if wrap else m
             out = []
             for _ in range(3):
                 w.zero_grad()
@@ -152,6 +152,21 @@ def test_ddp_world_size_one_with_two_streams_matches_unwrapped(no_dropout):
         plain, wrapped = run(False), run(True)
         for a, b in zip(plain, wrapped):
             _assert_same(a, b, "DDP vs plain")
+        # the two-phase exchange (in-place reduce_scatter_tensor into a shard OF the bucket + all_gather_into_tensor back) on RCCL
+        # itself - a group of one rank normally short-cuts to all_reduce - with fp32 and with bf16 buckets (round-4 review)
+        real_rs, calls = dist.reduce_scatter_tensor, []
+        dist.reduce_scatter_tensor = lambda *a, **k: (calls.append(a[0].numel()), real_rs(*a, **k))[1]
+        try:
+            direct = run(True, algorithm="direct", direct_at_world_size_one=True)
+        finally:
+            dist.reduce_scatter_tensor = real_rs
+        assert len(calls) > 9, "the direct exchange must have run (%d reduce_scatter launches)" % len(calls)
+        for a, b in zip(plain, direct):
+            _assert_same(a, b, "DDP direct (reduce_scatter + all_gather at world size 1) vs plain")
+        direct16 = run(True, algorithm="direct", direct_at_world_size_one=True, bucket_dtype=torch.bfloat16)
+        for a, b in zip(plain, direct16):
+            for n in a:
+                assert torch.allclose(a[n], b[n], rtol=1e-2, atol=1e-2 * float(a[n].abs().max()) + 1e-12), n
     finally:
         V.set_two_streams(prev)
         dist.destroy_process_group()

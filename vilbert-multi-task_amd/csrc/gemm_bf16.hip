@@ -357,12 +357,20 @@ __global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
     }
 }
 
+// persistent blocks per launch (VB_BF16_GRID, a multiple of 8, default = the 256 CUs): with fewer, two launches of
+// different streams share the chip side by side instead of one after the other
+inline int hb_grid_limit() {
+    static const int g = [] { const char* e = getenv("VB_BF16_GRID"); const int v = e ? atoi(e) : 256; return v >= 8 && v <= 256 ? v / 8 * 8 : 256; }();
+    return g;
+}
+
 template <int OUT, int EPI>
 int launch_hb(hipStream_t st, const HbP& p) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<OUT, EPI>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
     if (attr != hipSuccess) return (int)attr;
-    const int grid = p.tiles < 256 ? p.tiles : 256;
+    const int cus = hb_grid_limit();
+    const int grid = p.tiles < cus ? p.tiles : cus;
     hipLaunchKernelGGL((gemm_bf16_kernel<OUT, EPI>), dim3(grid), dim3(HB_THREADS), HB_LDS, st, p);
     VB_LAUNCH_CHECK();
     return 0;
@@ -866,10 +874,10 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     p.nkt = (p.M + HB_BK - 1) / HB_BK;
     // Contraction splits by a time model (measured with the laboratory flags, profiles/r05_bf16_lab_ablations.txt): a unit's
     // main loop costs ~1.0 us per contraction tile, its epilogue - 128 KiB of fp32 atomics that execute at the memory side,
-    // ~1.7 TB/s for the whole chip - ~0.075 us per unit IN FLIGHT ANYWHERE; rounds of 256 units. More splits shorten the main
+    // ~1.7 TB/s for the whole chip - ~0.075 us per unit IN FLIGHT ANYWHERE (0.12 in the model: in the step, where other streams compete for the memory side, fewer splits measured +0.7 %); rounds of 256 units. More splits shorten the main
     // loop and lengthen the atomics: the first version's "fill two rounds" rule spent 30 - 50 % of a launch in atomics.
     static const float t_k = [] { const char* e = getenv("VB_BF16_WG_TK"); return e ? (float)atof(e) : 1.0f; }();
-    static const float t_e = [] { const char* e = getenv("VB_BF16_WG_TE"); return e ? (float)atof(e) : 0.075f; }();
+    static const float t_e = [] { const char* e = getenv("VB_BF16_WG_TE"); return e ? (float)atof(e) : 0.12f; }();
     int best = 1;
     float best_t = 1e30f;
     for (int sp = 1; sp <= p.nkt && sp <= 64; ++sp) {
@@ -887,7 +895,8 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
     if (attr != hipSuccess) return (int)attr;
-    const int grid = p.units < 256 ? (p.units + 7) / 8 * 8 : 256;
+    const int cus = hb_grid_limit();
+    const int grid = p.units < cus ? (p.units + 7) / 8 * 8 : cus;
     hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(grid), dim3(HB_THREADS), HB_LDS, static_cast<hipStream_t>(stream), p);
     VB_LAUNCH_CHECK();
     return 0;

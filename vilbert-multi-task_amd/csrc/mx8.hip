@@ -240,7 +240,10 @@ enum { MX_OUT_F32 = 0, MX_OUT_BF16 = 1, MX_OUT_MX = 2 };
 
 template <int KIND, bool GELU, int RES>
 __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
-    constexpr bool TRANS = KIND == MX_OUT_MX;
+    // every launch uses the TRANSPOSED product since round 5: a lane owns ONE output row and 4-column groups of it, which
+    // pairs of half-waves turn into 16-byte stores (fp32: directly; bf16: after a v_permlane32_swap) - the epilogue of a
+    // persistent block is bound by store issue, and the natural map's 4- / 8-byte stores cost twice the instructions
+    constexpr bool TRANS = true;
     constexpr bool HAS_R = RES != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nk = p.K / MX_BK;
@@ -381,59 +384,60 @@ __global__ __launch_bounds__(MX_THREADS) void gemm_mx_kernel(const MxP p) {
 #else
         constexpr bool lab_store = true;
 #endif
-        if (!TRANS) {
-            // ---- natural map: acc[i][j][r] = row m0 + wm 64 + 32 i + 4 hi + (r & 3) + 8 (r >> 2), column nw + 2 l31 + j
-            const int col = nw + 2 * l31;
-            float2 bv = float2{0.f, 0.f};
-            if (p.bias != nullptr) bv = *reinterpret_cast<const float2*>(p.bias + col);
-            const bool full = m0 + MX_BM <= p.M;
+        if (KIND != MX_OUT_MX) {
+            // ---- fp32 / bf16 output on the transposed map: lane (l31, hi) holds row m of tile (i, j) and its columns
+            // nw + 32 j + 8 q + 4 hi + e in acc[i][j][4 q + e]
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int rbase = m0 + wm * 64 + 32 * i + 4 * hi;
-                float2 rv[16];
-                if (RES == 1) {
+                const int m = m0 + wm * 64 + 32 * i + l31;
+                const bool live = m < p.M && lab_store;
+                const long mr = m < p.M ? m : p.M - 1;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)   // clamped, never predicated (a per-element branch serialises the loads)
-                        rv[r] = *reinterpret_cast<const float2*>(p.R + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col);
-                } else if (RES == 2) {
-                    unsigned rw[16];
+                for (int j = 0; j < 2; ++j) {
+                    const int nb = nw + 32 * j;
+                    f32x4 rv[4];
+                    if (RES == 1) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        rw[r] = *reinterpret_cast<const unsigned*>(p.R16 + (long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr16 + col);
+                        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const f32x4*>(p.R + mr * p.ldr + nb + 8 * q + 4 * hi);
+                    } else if (RES == 2) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = float2{__uint_as_float(rw[r] << 16), __uint_as_float(rw[r] & 0xffff0000u)};
-                }
-                float2 v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v[r] = float2{acc[i][0][r] + bv.x, acc[i][1][r] + bv.y};
-                    if (GELU) v[r] = float2{mx_gelu(v[r].x), mx_gelu(v[r].y)};
-                    if (HAS_R) v[r] = float2{v[r].x + rv[r].x, v[r].y + rv[r].y};
-                }
-                if (KIND == MX_OUT_F32) {
-                    float* __restrict__ cp = p.C + (long)rbase * p.ldc + col;
-                    if (full && lab_store) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) *reinterpret_cast<float2*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc) = v[r];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (rbase + (r & 3) + 8 * (r >> 2) < p.M && (lab_store || v[r].x == 1234.5678f))
-                                *reinterpret_cast<float2*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldc) = v[r];
+                        for (int kq = 0; kq < 4; kq += 2) {
+                            // one 16-byte load per two 8-column groups (lanes 0-31: group kq, lanes 32-63: group kq + 1), then the
+                            // half-waves trade halves so that each lane holds ITS 4 columns of both groups
+                            const uint4 t = *reinterpret_cast<const uint4*>(p.R16 + mr * p.ldr16 + nb + 8 * (kq + hi));
+                            const auto sx = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+                            rv[kq] = f32x4{__uint_as_float(sx[0] << 16), __uint_as_float(sx[0] & 0xffff0000u),
+                                           __uint_as_float(sy[0] << 16), __uint_as_float(sy[0] & 0xffff0000u)};
+                            rv[kq + 1] = f32x4{__uint_as_float(sx[1] << 16), __uint_as_float(sx[1] & 0xffff0000u),
+                                               __uint_as_float(sy[1] << 16), __uint_as_float(sy[1] & 0xffff0000u)};
+                        }
                     }
-                } else {
-                    unsigned short* __restrict__ cp = p.Cb + (long)rbase * p.ldb16 + col;
-                    if (full && lab_store) {
+                    uint2 o2[4];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            *reinterpret_cast<unsigned*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldb16) =
-                                (unsigned)bf16_rne(v[r].x) | ((unsigned)bf16_rne(v[r].y) << 16);
-                    } else {
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.bias != nullptr) v = *reinterpret_cast<const f32x4*>(p.bias + nb + 8 * q + 4 * hi);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (rbase + (r & 3) + 8 * (r >> 2) < p.M && (lab_store || v[r].x == 1234.5678f))
-                                *reinterpret_cast<unsigned*>(cp + (long)((r & 3) + 8 * (r >> 2)) * p.ldb16) =
-                                    (unsigned)bf16_rne(v[r].x) | ((unsigned)bf16_rne(v[r].y) << 16);
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] += acc[i][j][4 * q + e];
+                            if (GELU) v[e] = mx_gelu(v[e]);
+                        }
+                        if (HAS_R) v += rv[q];
+                        if (KIND == MX_OUT_F32) {
+                            if (live) *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + nb + 8 * q + 4 * hi) = v;
+                        } else {
+                            o2[q] = uint2{(unsigned)bf16_rne(v[0]) | ((unsigned)bf16_rne(v[1]) << 16),
+                                          (unsigned)bf16_rne(v[2]) | ((unsigned)bf16_rne(v[3]) << 16)};
+                        }
+                    }
+                    if (KIND == MX_OUT_BF16) {
+#pragma unroll
+                        for (int kq = 0; kq < 4; kq += 2) {
+                            const auto sx = __builtin_amdgcn_permlane32_swap(o2[kq].x, o2[kq + 1].x, false, false);
+                            const auto sy = __builtin_amdgcn_permlane32_swap(o2[kq].y, o2[kq + 1].y, false, false);
+                            if (live) *reinterpret_cast<uint4*>(p.Cb + (long)m * p.ldb16 + nb + 8 * (kq + hi)) = uint4{sx[0], sy[0], sx[1], sy[1]};
+                        }
                     }
                 }
             }
@@ -573,13 +577,13 @@ extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {
     if (a->a_srows < (a->M + MX_BM - 1) / MX_BM * MX_BM || a->w_srows < a->N || a->a_srows % 4 != 0 || a->w_srows % 4 != 0)
         return VB_E_RANGE;
     if (a->C != nullptr && (a->ldc % 4 != 0 || a->ldc < a->N || !vb_aligned16(a->C))) return VB_E_ALIGN;
-    if (a->Cb != nullptr && (a->ldb16 % 4 != 0 || a->ldb16 < a->N || (reinterpret_cast<uintptr_t>(a->Cb) & 7u) != 0)) return VB_E_ALIGN;
+    if (a->Cb != nullptr && (a->ldb16 % 8 != 0 || a->ldb16 < a->N || !vb_aligned16(a->Cb))) return VB_E_ALIGN;
     if (a->Cq != nullptr && (a->ldq % 16 != 0 || a->ldq < a->N || !vb_aligned16(a->Cq) || a->c_srows < a->M)) return VB_E_ALIGN;
     if (a->residual != nullptr && (a->ldr % 4 != 0 || a->ldr < a->N || !vb_aligned16(a->residual))) return VB_E_ALIGN;
     if (a->bias != nullptr && !vb_aligned16(a->bias)) return VB_E_ALIGN;
     if (a->residual != nullptr && a->ldr % 2 != 0) return VB_E_ALIGN;
     if (a->residual != nullptr && a->residual_bf16 != nullptr) return VB_E_BADARG;
-    if (a->residual_bf16 != nullptr && (a->ldr16 % 4 != 0 || a->ldr16 < a->N || (reinterpret_cast<uintptr_t>(a->residual_bf16) & 7u) != 0))
+    if (a->residual_bf16 != nullptr && (a->ldr16 % 8 != 0 || a->ldr16 < a->N || !vb_aligned16(a->residual_bf16)))
         return VB_E_ALIGN;
     if ((long)a->M * a->lda > 0xffffffffL && a->lda * 256 > 0xffffffffL) return VB_E_RANGE;
     MxP p{};

@@ -73,7 +73,7 @@ class DistributedDataParallel(nn.Module):
     "module")`` when saving, train_concap.py:662-664)."""
 
     def __init__(self, module, delay_allreduce=False, message_size=16 * 1024 * 1024, process_group=None,
-                 algorithm=None, bucket_dtype=None, **_unused):
+                 algorithm=None, bucket_dtype=None, direct_at_world_size_one=None, **_unused):
         super(DistributedDataParallel, self).__init__()
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed.init_process_group must be called first")
@@ -85,6 +85,12 @@ class DistributedDataParallel(nn.Module):
         if bucket_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("bucket_dtype must be None / torch.float32 / torch.bfloat16")
         self.algorithm = algorithm
+        # A group of ONE rank normally takes the plain all_reduce (nothing to exchange). direct_at_world_size_one (or
+        # VB_DDP_FORCE_DIRECT=1) sends it through the in-place reduce_scatter_tensor(shard of buf) + all_gather_into_tensor pair
+        # anyway, so that the two-phase exchange runs on RCCL on a single-GPU box (tests/test_arena_gpu.py, bench.py --force-ddp
+        # --ddp-algorithm direct); results are unchanged.
+        self.direct_at_world_size_one = bool(int(os.environ.get("VB_DDP_FORCE_DIRECT", "0"))) \
+            if direct_at_world_size_one is None else bool(direct_at_world_size_one)
         self.bucket_dtype = None if bucket_dtype in (None, torch.float32) else bucket_dtype
         self.module = module
         self.delay_allreduce = delay_allreduce
@@ -188,7 +194,7 @@ class DistributedDataParallel(nn.Module):
                 b.stage = torch.empty(b.flat.numel(), dtype=self.bucket_dtype, device=b.flat.device)
             b.stage.copy_(b.flat)                 # round to the exchange precision (one elementwise pass)
             buf = b.stage
-        if self.algorithm == "ring" or self.world_size == 1:
+        if self.algorithm == "ring" or (self.world_size == 1 and not self.direct_at_world_size_one):
             b.work = [dist.all_reduce(buf, op=op, group=self.group, async_op=True)]
         else:
             # two-phase exchange, both phases in place: this rank's shard is a view of the range
