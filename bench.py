@@ -844,7 +844,9 @@ def main():
         sps = world * B * args.steps / elapsed
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_note = None, "not measured"
-        tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_gemm_traffic.json")
+        if not os.path.isfile(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r03_gemm_traffic.json")
         if not os.path.isfile(tpath):
             tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
         if os.path.isfile(tpath):
