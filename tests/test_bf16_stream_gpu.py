@@ -5,8 +5,8 @@ that replaces the reference's `model.half()` + apex FP16_Optimizer (/root/refere
 Bars (this mode's own - it is outside the fp32 1e-4 bar by construction and never the default):
   * every kernel against float64 arithmetic on the SAME bf16 operand values: the only errors allowed are the fp32
     accumulation (<= 3e-6 sum|a b|) and ONE bf16 rounding of the result (|want| / 256);
-  * the attention kernels are the fp32 kernels with bf16 loads / stores: their outputs must equal the fp32 kernels' outputs
-    on the same values rounded to bf16, bit for bit;
+  * the attention kernels are the fp32 kernels' source with bf16 loads / stores and bf16 MFMA: within 1.5e-2 relative L2 of the
+    fp32 kernels on the same values (probabilities / dS and the outputs are rounded to bf16), log-sum-exp to 1e-5;
   * dropout masks are the fp32 path's (same (seed, element index) function): checked against vb_dropout;
   * model level: forward drift against the fp32 oracle bounded and printed; every parameter gradient against the exact-fp32
     mode (relative L2 per tensor, median / 90th percentile / worst printed and bounded); 200 AdamW steps track the fp32 CPU
@@ -146,7 +146,12 @@ def test_layernorm16_forward_backward(rows, cols):
 
 @pytest.mark.parametrize("B,heads,d,Sq,Sk,drop", [(3, 12, 64, 36, 36, 0.0), (2, 8, 128, 37, 37, 0.1), (2, 8, 128, 36, 37, 0.0),
                                                    (2, 8, 128, 24, 101, 0.1), (1, 4, 64, 101, 24, 0.0), (2, 2, 32, 9, 7, 0.0)])
-def test_attention16_is_the_fp32_kernel_with_bf16_loads_and_stores(B, heads, d, Sq, Sk, drop):
+def test_attention16_matches_the_fp32_kernels_on_the_same_values(B, heads, d, Sq, Sk, drop):
+    """csrc/attention.hip compiled with -DVB_ATTN_BF16: bf16 loads / stores of q, k, v, ctx and their gradients, and the
+    contractions on v_mfma_f32_16x16x16_bf16. Q K^T and dO V^T see exact bf16 operands (fp32 accumulation in another order:
+    the log-sum-exp agrees to ~1e-6); probabilities and dS are rounded to bf16 (2^-9) on their way into the second
+    contraction and the results once more on their way out: every output within 1.5e-2 relative L2 and 2^-6 of its range of
+    the fp32 kernels run on the same values (same dropout mask: (seed, element index))."""
     from vilbert import ops, ops16
     H = heads * d
     qkv_q = (_rand(B, Sq, 3 * H, seed=Sq) * 0.7).to(BF16).to(DEV)
@@ -161,17 +166,25 @@ def test_attention16_is_the_fp32_kernel_with_bf16_loads_and_stores(B, heads, d, 
     f_q, f_k = qkv_q.float(), qkv_k.float()
     q32, k32, v32 = f_q[..., :H], f_k[..., H:2 * H], f_k[..., 2 * H:]
     out32, _, lse32 = ops.attention_fwd(q32, k32, v32, mask, heads, False, True, drop, seed)
-    assert out16.dtype == BF16 and torch.equal(lse16, lse32)
-    assert torch.equal(out16, out32.to(BF16)), "%d elements differ" % int((out16 != out32.to(BF16)).sum())
+    assert out16.dtype == BF16 and torch.allclose(lse16, lse32, rtol=1e-5, atol=1e-5)
+
+    def close(got, want, nm):
+        got, want = got.double(), want.double()
+        assert torch.isfinite(got).all(), nm
+        l2 = float((got - want).norm() / want.norm().clamp_min(1e-30))
+        mx = float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        assert l2 <= 1.5e-2 and mx <= 2.0 ** -6, "%s: relative L2 %.3e, max error %.3e of the range" % (nm, l2, mx)
+        return l2
+    e_o = close(out16, out32, "context")
     dq16 = torch.empty(B, Sq, 3 * H, dtype=BF16, device=DEV)
     dk16 = torch.empty(B, Sk, 3 * H, dtype=BF16, device=DEV)
     ops16.attention_bwd(d_out, q16, k16, v16, mask, heads, lse16, dq16[..., :H], dk16[..., H:2 * H], dk16[..., 2 * H:], drop, seed)
     dq32 = torch.empty(B, Sq, 3 * H, device=DEV)
     dk32 = torch.empty(B, Sk, 3 * H, device=DEV)
     ops.attention_bwd(d_out.float(), q32, k32, v32, mask, heads, lse32, dq32[..., :H], dk32[..., H:2 * H], dk32[..., 2 * H:], drop, seed)
-    for got, want, nm in ((dq16[..., :H], dq32[..., :H], "dq"), (dk16[..., H:2 * H], dk32[..., H:2 * H], "dk"),
-                          (dk16[..., 2 * H:], dk32[..., 2 * H:], "dv")):
-        assert torch.equal(got, want.to(BF16)), "%s: %d elements differ" % (nm, int((got != want.to(BF16)).sum()))
+    errs = [close(got, want, nm) for got, want, nm in ((dq16[..., :H], dq32[..., :H], "dq"), (dk16[..., H:2 * H], dk32[..., H:2 * H], "dk"),
+                                                       (dk16[..., 2 * H:], dk32[..., 2 * H:], "dv"))]
+    print("bf16 attention %dx%d d=%d p=%.1f: relative L2 vs the fp32 kernels - ctx %.2e dq %.2e dk %.2e dv %.2e" % ((Sq, Sk, d, drop, e_o) + tuple(errs)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------

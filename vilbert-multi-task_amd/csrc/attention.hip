@@ -103,14 +103,49 @@ __device__ __forceinline__ void load_frag(f32x4 (&f)[DS], const io_t* p) {
     for (int s = 0; s < DS; ++s) f[s] = ld4(p + 16 * s);
 }
 
+// The two contraction patterns of these kernels. fp32 build: v_mfma_f32_16x16x4_f32, four instructions per 16 contraction
+// values (lane group g supplies index 4 g + e in step e). bf16 build (VB_ATTN_BF16): ONE v_mfma_f32_16x16x16_bf16 per 16 values -
+// its operand layout is exactly "lane group g holds the contraction indices 4 g .. 4 g + 3", i.e. the four fp32 operands of
+// the four steps packed into one register pair - a quarter of the matrix instructions, each at the bf16 rate. Q, K, V and dO
+// ARE bf16 values there (widened on their way in), so their products are exact as before; probabilities and dS are rounded
+// to bf16 (2^-9 relative) on their way into the second contraction, accumulation stays fp32.
+#ifdef VB_ATTN_BF16
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 pk4(const f32x4 v) {
+    return __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4_t));     // v_cvt_pk_bf16_f32: round to nearest even
+}
+#endif
+
 template <int DS>
 __device__ __forceinline__ f32x4 dot_tile(const f32x4 (&a)[DS], const f32x4 (&b)[DS]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < DS; ++s)
+    for (int s = 0; s < DS; ++s) {
+#ifdef VB_ATTN_BF16
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk4(a[s]), pk4(b[s]), acc, 0, 0, 0);
+#else
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][e], b[s][e], acc, 0, 0, 0);
+#endif
+    }
     return acc;
+}
+
+// acc[dt] += sum_r a[r] b[dt][r]: the rank-4 update of the second contractions (a[r] = this lane's probability / dS value of
+// contraction index 4 g + r, b[dt][r] = the operand row of that index at column 16 dt + c)
+template <int DS>
+__device__ __forceinline__ void mma_rank4(f32x4 (&acc)[DS], const f32x4 a, const f32x4 (&b)[DS]) {
+#ifdef VB_ATTN_BF16
+    const s16x4 pa = pk4(a);
+#pragma unroll
+    for (int dt = 0; dt < DS; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pk4(b[dt]), acc[dt], 0, 0, 0);
+#else
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DS; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[dt][r], acc[dt], 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ float group_max(float v) {
@@ -262,17 +297,16 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
         if (kt < nkt) {
+            f32x4 av, bv[DS];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = min(kt * 16 + 4 * g + r, p.n_k - 1);  // the A operand is 0 past n_k
                 const io_t* rp = rbase + (long)key * ldr;
-                float vv[DS];
+                av[r] = st[kt][r];
 #pragma unroll
-                for (int dt = 0; dt < DS; ++dt) vv[dt] = ld1(rp + 16 * dt);
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt)
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
+                for (int dt = 0; dt < DS; ++dt) bv[dt][r] = ld1(rp + 16 * dt);
             }
+            mma_rank4<DS>(oacc, av, bv);
         }
     }
 
@@ -332,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
         load_frag<DS>(dof, dobase + (long)q_row * p.lddo + 4 * g);
         const f32x4 s = dot_tile<DS>(qf, kf);    // S[q = 16 qt + 4g + r][key = c]
         const f32x4 dpr = dot_tile<DS>(dof, vf);  // dO V^T, same layout
-        float pd[4], dsv[4];
+        f32x4 pd, dsv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + 4 * g + r;
@@ -353,23 +387,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnP p_in) {
             dsv[r] = dsr;
         }
         // dV[key][d] += sum_q Pdrop[q][key] dO[q][d];  dK[key][d] += sum_q dS[q][key] Q[q][d]
+        f32x4 dov[DS], qv[DS];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = min(qt * 16 + 4 * g + r, p.n_q - 1);  // A operands are 0 past n_q
             const io_t* dop = dobase + (long)q * p.lddo + c;
             const io_t* qp = qbase + (long)q * p.ldq + c;
-            float dov[DS], qv[DS];
 #pragma unroll
             for (int dt = 0; dt < DS; ++dt) {
-                dov[dt] = ld1(dop + 16 * dt);
-                qv[dt] = ld1(qp + 16 * dt);
-            }
-#pragma unroll
-            for (int dt = 0; dt < DS; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[r], dov[dt], dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[r], qv[dt], dk[dt], 0, 0, 0);
+                dov[dt][r] = ld1(dop + 16 * dt);
+                qv[dt][r] = ld1(qp + 16 * dt);
             }
         }
+        mma_rank4<DS>(dv, pd, dov);
+        mma_rank4<DS>(dk, dsv, qv);
     }
 
     // D[row = key = 4g + r][col = d = 16 dt + c]
@@ -568,16 +599,15 @@ __global__ __launch_bounds__(256, 3) void attn_q_lds_kernel(const AttnP p_in) { 
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             if (kt < nkt) {
+                f32x4 av, bv[DS];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float* rp = rb + (kt * 16 + 4 * g + r) * LD;
-                    float vv[DS];
+                    av[r] = st[kt][r];
 #pragma unroll
-                    for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
-#pragma unroll
-                    for (int dt = 0; dt < DS; ++dt)
-                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[kt][r], vv[dt], oacc[dt], 0, 0, 0);
+                    for (int dt = 0; dt < DS; ++dt) bv[dt][r] = rp[16 * dt];
                 }
+                mma_rank4<DS>(oacc, av, bv);
             }
         }
         io_t* obase = BWD ? p.dQ : p.O;
@@ -633,7 +663,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
             load_frag_lds<DS>(dof, sO + (qt * 16 + c) * LD + 4 * g);
             const f32x4 s = dot_tile<DS>(qf, kf);
             const f32x4 dpr = dot_tile<DS>(dof, vf);
-            float pd[4], dsv[4];
+            f32x4 pd, dsv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = qt * 16 + 4 * g + r;
@@ -653,22 +683,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_lds_kernel(const AttnP p_in) 
                 pd[r] = pdr;
                 dsv[r] = dsr;
             }
+            f32x4 dov[DS], qv[DS];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* dop = sO + (qt * 16 + 4 * g + r) * LD + c;
                 const float* qp = sQ + (qt * 16 + 4 * g + r) * LD + c;
-                float dov[DS], qv[DS];
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt) {
-                    dov[dt] = dop[16 * dt];
-                    qv[dt] = qp[16 * dt];
-                }
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[r], dov[dt], dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv[r], qv[dt], dk[dt], 0, 0, 0);
+                    dov[dt][r] = dop[16 * dt];
+                    qv[dt][r] = qp[16 * dt];
                 }
             }
+            mma_rank4<DS>(dv, pd, dov);
+            mma_rank4<DS>(dk, dsv, qv);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -815,16 +842,15 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             if (kt < nkt) {
+                f32x4 av, bv[DS];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float* rp = sK + min(kt * 16 + 4 * g + r, p.n_k - 1) * LD + c;
-                    float vv[DS];
+                    av[r] = dsm[kt][r];
 #pragma unroll
-                    for (int dt = 0; dt < DS; ++dt) vv[dt] = rp[16 * dt];
-#pragma unroll
-                    for (int dt = 0; dt < DS; ++dt)
-                        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsm[kt][r], vv[dt], oacc[dt], 0, 0, 0);
+                    for (int dt = 0; dt < DS; ++dt) bv[dt][r] = rp[16 * dt];
                 }
+                mma_rank4<DS>(oacc, av, bv);
             }
         }
 #pragma unroll
@@ -859,27 +885,24 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_lds_kernel(const AttnP p_i
             dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int q4 = 0; q4 < p.n_q; q4 += 16) {
+            f32x4 pd, dsv, dov[DS], qv[DS];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q4 + 4 * g + r;
                 const int qr = min(q, p.n_q - 1);
                 // A operands: Pd^T / dS^T element (key = c, q); queries past n_q contribute exactly 0
-                const float pd = q < p.n_q ? sP[qr * LDP + key] : 0.f;
-                const float dsv = q < p.n_q ? sS[qr * LDP + key] : 0.f;
+                pd[r] = q < p.n_q ? sP[qr * LDP + key] : 0.f;
+                dsv[r] = q < p.n_q ? sS[qr * LDP + key] : 0.f;
                 const float* dop = sO + qr * LD + c;
                 const float* qp = sQ + qr * LD + c;
-                float dov[DS], qv[DS];
 #pragma unroll
                 for (int dt = 0; dt < DS; ++dt) {
-                    dov[dt] = dop[16 * dt];
-                    qv[dt] = qp[16 * dt];
-                }
-#pragma unroll
-                for (int dt = 0; dt < DS; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd, dov[dt], dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv, qv[dt], dk[dt], 0, 0, 0);
+                    dov[dt][r] = dop[16 * dt];
+                    qv[dt][r] = qp[16 * dt];
                 }
             }
+            mma_rank4<DS>(dv, pd, dov);
+            mma_rank4<DS>(dk, dsv, qv);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
