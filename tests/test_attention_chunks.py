@@ -65,3 +65,17 @@ def test_attention_over_more_than_320_keys(B, heads, d, Sq, Sk, kb):
     assert (out.cpu().double() - want).abs().max().item() <= 1e-5 and (lse.cpu().double() - want_lse).abs().max().item() <= 1e-4
     with pytest.raises(RuntimeError, match="keys"):
         ops.attention_fwd(q.to(dev), dkv[..., :H], dkv[..., H:], mask.to(dev), heads, drop_p=0.1, seed=1)
+
+
+@pytest.mark.gpu
+def test_more_than_320_keys_under_autograd_says_so_at_the_call():
+    """Round-4 advisor: the chunked path is forward-only; under autograd the error used to appear inside backward()
+    (VB_E_RANGE, no hint). It is raised where the attention is called, with the reason."""
+    from vilbert import functional as VF
+    H, heads, S = 128, 2, 400
+    qkv = torch.randn(1, S, 3 * H, device="cuda:0", requires_grad=True)
+    with pytest.raises(RuntimeError, match="under autograd"):
+        VF.self_attention(qkv, None, heads)
+    with torch.no_grad():
+        ctx, _ = VF.self_attention(qkv, None, heads)        # inference: served chunk by chunk
+    assert ctx.shape == (1, S, H) and torch.isfinite(ctx).all()

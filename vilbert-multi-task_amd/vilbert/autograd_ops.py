@@ -297,12 +297,22 @@ def dropout(x, p, residual=None):
     return DropoutFn.apply(x, residual, p)
 
 
+def _check_keys_for_backward(n_keys):
+    """More than ops.MAX_KEYS keys are served chunk by chunk in INFERENCE only (ops._attention_fwd_long); under autograd the
+    backward kernels would refuse much later (VB_E_RANGE inside backward()) - say so where the call is made."""
+    if n_keys > ops.MAX_KEYS:
+        raise RuntimeError("attention: %d keys under autograd - one launch (and its backward) serves at most %d keys; longer "
+                           "key sequences (stacked retrieval options, in_batch_pairs) are supported in inference (no_grad) only"
+                           % (n_keys, ops.MAX_KEYS))
+
+
 class SelfAttnFn(Function):
     """ctx = attention over one fused [q | k | v] projection; dqkv is written in one buffer."""
 
     @staticmethod
     def forward(ctx, qkv, mask_add, heads, drop_p, want_probs):
         H = qkv.shape[-1] // 3
+        _check_keys_for_backward(qkv.shape[1])
         seed = next_seed() if drop_p > 0.0 else 0
         out, probs, lse = ops.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads,
                                             want_probs, True, drop_p, seed)
@@ -335,6 +345,7 @@ class BiAttnFn(Function):
     @staticmethod
     def forward(ctx, qkv1, qkv2, mask1, mask2, heads, p1, p2, want_probs):
         H = qkv1.shape[-1] // 3
+        _check_keys_for_backward(max(qkv1.shape[1], qkv2.shape[1]))
         s1 = next_seed() if p1 > 0.0 else 0
         s2 = next_seed() if p2 > 0.0 else 0
         q1, k1, v1 = qkv1[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:]
