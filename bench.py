@@ -528,6 +528,66 @@ def main():
         del net, optim
         return out
 
+    def task_legs():
+        """Fine-tuning steps at the reference's task shapes (BASELINE configs[3] direction, on the base 6L/6C model): the
+        VILBertForVLTasks forward + backward + AdamW with the losses of vilbert/task_utils.py:325-341 -
+          * vqa: batch 128, 23 tokens, 101 regions (vilbert_tasks.yml:12-14), BCEWithLogits on the 3,129-way answer head,
+            loss.mean() * target.size(1);
+          * retrieval: batch 64 x 4 candidate captions = 256 sequences, 30 tokens, 101 regions (vilbert_tasks.yml TASK7/8),
+            CrossEntropy over the 4 vil_logit scores of a group -
+        once on the fp32 kernels and once in the bf16 training mode (the key-ragged attention launches: 101 keys per row)."""
+        from vilbert.optim import AdamW
+        out = {}
+        with torch.device(device):
+            net = build_model(cfg, "vltasks", device).train()
+        decay = [p for n_, p in net.named_parameters() if not any(k in n_ for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+        no_decay = [p for n_, p in net.named_parameters() if any(k in n_ for k in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+        optim = AdamW([{"params": decay, "weight_decay": 0.01}, {"params": no_decay, "weight_decay": 0.0}], lr=4e-5)
+        fnames = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask"]
+        g = torch.Generator().manual_seed(11)
+        bce = torch.nn.BCEWithLogitsLoss(reduction="mean")
+        xe = torch.nn.CrossEntropyLoss()
+        for tag, (pb, T, R) in (("vqa_b128", (128, 23, 101)), ("retrieval_b64x4", (256, 30, 101))):
+            xb = synthetic_batch(cfg, pb, T, R, 7, False)
+            inp = tuple(xb[n].to(device) for n in fnames)
+            if tag.startswith("vqa"):
+                target = torch.zeros(pb, 3129)
+                target[torch.arange(pb), torch.randint(0, 3129, (pb,), generator=g)] = 1.0
+                target = target.to(device)
+            else:
+                target = torch.zeros(pb // 4, dtype=torch.long, device=device)
+
+            def t():
+                optim.zero_grad(set_to_none=True)
+                o = net(*inp)
+                if tag.startswith("vqa"):
+                    loss = bce(o[0], target).mean() * target.size(1)
+                else:
+                    loss = xe(o[2].view(pb // 4, 4), target)
+                loss.backward()
+                optim.step()
+                return loss
+            for mode in ("f32", "bf16"):
+                _native.set_gemm_mode(mode)
+                try:
+                    n = max(6, args.steps // 2)
+                    dt = timed(t, 3, n)
+                    tf, launches = gemm_family_tf(t)
+                finally:
+                    _native.set_gemm_mode("f32")
+                peak = PEAK_FP32_MFMA_TFLOPS if mode == "f32" else 2500.0
+                out["task_train_%s_%s" % (tag, mode)] = {
+                    "value": round(pb * n / dt, 2), "unit": "sequences/s", "ms_per_step": round(1e3 * dt / n, 3), "steps": n,
+                    "batch": pb, "tokens": T, "regions": R, "gemm_family_tflops": round(tf, 1), "gemm_launches_per_step": launches,
+                    "gemm_frac_of_mfma_peak": round(tf / peak, 4), "dtype": "f32" if mode == "f32" else BF16_DTYPE,
+                    "note": "VILBertForVLTasks fine-tuning step (fwd + bwd + AdamW, dropout on) at the %s task shape, one GPU" %
+                            ("VQA (BCEWithLogits, 3,129 answers)" if tag.startswith("vqa") else
+                             "image-retrieval (4 captions per image, CrossEntropy over vil_logit)")}
+        if optim._arena is not None:
+            optim._arena.release()
+        del net, optim
+        return out
+
     if args.mode == "fwd":
         step, x, model = forward_workload(B)
         n_reg = N_REG
@@ -827,6 +887,8 @@ def main():
         del fstep, fmodel
         torch.cuda.empty_cache()
         extra.update(large_legs())
+        torch.cuda.empty_cache()
+        extra.update(task_legs())
         torch.cuda.empty_cache()
 
     if rank == 0:

@@ -43,6 +43,22 @@ constexpr int HB_LDS = HB_S * HB_STAGE;         // 147,456
 constexpr int HB_LW = 2;
 constexpr int HB_MFMA_WAVES = 8, HB_THREADS = 64 * (HB_MFMA_WAVES + 2 * HB_LW);
 
+// Block shapes of the NT kernel. HbFull: the geometry above, ONE block per CU. HbHalf: 128 x 128 tiles, 4 MFMA waves (2 x 2) + one
+// loader wave per operand, a 2-stage ring of 32 KiB stages = 64 KiB, so that TWO independent blocks share a CU: while one block
+// is in its epilogue - during which the full-size kernel's CU computes nothing (section 4.5 of DESIGN.md: 30 - 50 % of a
+// short-K multi-round launch) - the other one's MFMAs keep the matrix pipe busy, and each block's single tile of DMA lookahead
+// is covered by its neighbour as well.
+template <int BM_, int S_, int LW_>
+struct HbCfg {
+    static constexpr int BM = BM_, S = S_, LW = LW_;
+    static constexpr int A = BM * HB_ROWB, B = HB_BN * HB_ROWB, STAGE = A + B, LDS = S * STAGE;
+    static constexpr int MW = BM / 32;                       // MFMA waves: (BM / 64) x 2
+    static constexpr int THREADS = 64 * (MW + 2 * LW);
+    static constexpr int PER_CU = BM == 256 ? 1 : 2;
+};
+using HbFull = HbCfg<256, 3, 2>;
+using HbHalf = HbCfg<128, 2, 1>;
+
 __device__ __forceinline__ unsigned short bf16_rne(float v) {
     const unsigned u = __float_as_uint(v);
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
@@ -91,6 +107,7 @@ struct HbP {
     float* C32; long ldc32;
     unsigned short* D; long ldd;           // gelu'(pre) out (HB_GELU), may be null
     int tiles_n, tiles;
+    int bm;      // rows of an output tile (256 or 128)
     float drop_p, drop_scale;
     uint64_t seed;
     const uint64_t* epoch;
@@ -111,7 +128,7 @@ __device__ __forceinline__ bool hb_origin(const HbP& p, int b, int it, int grid,
         r = t / p.tiles_n;
         c = t % p.tiles_n;
     }
-    m0 = r * HB_BM;
+    m0 = r * p.bm;
     n0 = c * HB_BN;
     return true;
 }
@@ -119,10 +136,11 @@ __device__ __forceinline__ bool hb_origin(const HbP& p, int b, int it, int grid,
 // Loader wave of one operand of the NT kernel: ND DMAs (8 tile rows of 128 bytes each) per K tile. LDS rows of 128 bytes,
 // the eight 16-byte chunks of a row XOR-swizzled with (row >> 1) & 7 (fragment ds_read_b128 conflict-free); the DMA writes
 // lane-linear, so the swizzle is applied on the SOURCE address.
-template <int ND_ALL, bool IS_A>
+template <class Cfg, bool IS_A>
 __device__ __forceinline__ void hb_loader(const HbP& p, const unsigned lds0, const int lane, const int nk, const int rounds,
                                           const int widx) {
-    constexpr int ND = ND_ALL / HB_LW;             // this wave's share: DMAs widx, widx + HB_LW, ...
+    constexpr int HB_LW = Cfg::LW, HB_S = Cfg::S, HB_STAGE = Cfg::STAGE, HB_A = Cfg::A;      // (shadow the full-size constants)
+    constexpr int ND = (IS_A ? Cfg::A : Cfg::B) / 1024 / HB_LW;             // this wave's share: DMAs widx, widx + HB_LW, ...
     const unsigned short* const mat = IS_A ? p.A : p.B;
     const long ld = IS_A ? p.lda : p.ldb;
     const int nrows = IS_A ? p.M : p.N;
@@ -161,30 +179,37 @@ __device__ __forceinline__ void hb_loader(const HbP& p, const unsigned lds0, con
     set_tile(0);
     __builtin_amdgcn_s_setprio(2);
     for (int s = 0; s < HB_S && s < total; ++s) issue_next();
-    if (total >= 2) hb_wait_vm<ND>(); else hb_wait_vm<0>();     // K tile 0 has landed (at most the newest tile is pending)
+    // K tile 0 has landed (S - 2 of the newer tiles may still be pending)
+    if (total >= 2) hb_wait_vm<(HB_S - 2) * ND>(); else hb_wait_vm<0>();
     __builtin_amdgcn_s_barrier();                                 // P0
     for (int g = 0; g < total; ++g) {
-        // K tile g + 1 has landed: issued so far = min(total, g + 3) tiles, so at most tile g + 2 may be pending
-        if (g + 3 <= total) hb_wait_vm<ND>(); else hb_wait_vm<0>();
+        // K tile g + 1 has landed: issued so far = min(total, g + S) tiles, so at most S - 2 newer tiles may be pending
+        if (g + HB_S <= total) hb_wait_vm<(HB_S - 2) * ND>(); else hb_wait_vm<0>();
         __builtin_amdgcn_s_barrier();                             // B_g: stage g has been read completely
-        if (g + 3 < total) issue_next();
+        if (g + HB_S < total) issue_next();
     }
 }
 
-template <int OUT, int EPI>
-__global__ __launch_bounds__(HB_THREADS) void gemm_bf16_kernel(const HbP p) {
+template <int OUT, int EPI, class Cfg>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::PER_CU == 1 ? 1 : 3) void gemm_bf16_kernel(const HbP p) {
+    constexpr int HB_MFMA_WAVES = Cfg::MW, HB_LW = Cfg::LW, HB_S = Cfg::S, HB_STAGE = Cfg::STAGE, HB_A = Cfg::A;   // (shadow)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nk = p.K / HB_BK;
     const int b = blockIdx.x, grid = gridDim.x;
     int rounds = 0;
     while (rounds * grid < p.tiles && hb_tile_of(b, rounds, grid, p.tiles) >= 0) ++rounds;
     if (rounds == 0) return;
+    if (Cfg::PER_CU == 2 && (p.flags & 16) && b >= grid / 2) {
+        // laboratory: the second block of a CU starts half an output tile late, so that the two are never in their epilogues
+        // at the same time (timing experiments only; they de-phase on their own after the first tile)
+        for (int i = 0; i < nk * 8; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= HB_MFMA_WAVES) {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
         const int lw = wave - HB_MFMA_WAVES;
-        if (lw < HB_LW) hb_loader<HB_A / 1024, true>(p, lds0, threadIdx.x & 63, nk, rounds, lw);
-        else hb_loader<HB_B / 1024, false>(p, lds0, threadIdx.x & 63, nk, rounds, lw - HB_LW);
+        if (lw < HB_LW) hb_loader<Cfg, true>(p, lds0, threadIdx.x & 63, nk, rounds, lw);
+        else hb_loader<Cfg, false>(p, lds0, threadIdx.x & 63, nk, rounds, lw - HB_LW);
         return;
     }
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -364,16 +389,29 @@ inline int hb_grid_limit() {
     return g;
 }
 
-template <int OUT, int EPI>
-int launch_hb(hipStream_t st, const HbP& p) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<OUT, EPI>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, HB_LDS);
+template <int OUT, int EPI, class Cfg>
+int launch_hb_cfg(hipStream_t st, HbP p) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<OUT, EPI, Cfg>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (attr != hipSuccess) return (int)attr;
-    const int cus = hb_grid_limit();
-    const int grid = p.tiles < cus ? p.tiles : cus;
-    hipLaunchKernelGGL((gemm_bf16_kernel<OUT, EPI>), dim3(grid), dim3(HB_THREADS), HB_LDS, st, p);
+    p.bm = Cfg::BM;
+    p.tiles = ((p.M + Cfg::BM - 1) / Cfg::BM) * p.tiles_n;
+    const int slots = hb_grid_limit() * Cfg::PER_CU;
+    const int grid = p.tiles < slots ? p.tiles : slots;
+    hipLaunchKernelGGL((gemm_bf16_kernel<OUT, EPI, Cfg>), dim3(grid), dim3(Cfg::THREADS), Cfg::LDS, st, p);
     VB_LAUNCH_CHECK();
     return 0;
+}
+
+// VB_BF16_HALF: 0 = always the full-size block, 2 = always two half-size blocks per CU, 1 (default) = the half-size blocks for
+// launches whose 256-row tiles need more than one round of the 256 CUs AND have a short contraction (K <= 1024) - the launches
+// whose epilogue is not hidden by anything (profiles/r05_bf16_lab_ablations.txt)
+template <int OUT, int EPI>
+int launch_hb(hipStream_t st, const HbP& p) {
+    static const int half = [] { const char* e = getenv("VB_BF16_HALF"); return e ? atoi(e) : 1; }();
+    const int tiles_full = ((p.M + 255) / 256) * p.tiles_n;
+    const bool use_half = half == 2 || (half == 1 && tiles_full > 256 && p.K <= 1024);
+    return use_half ? launch_hb_cfg<OUT, EPI, HbHalf>(st, p) : launch_hb_cfg<OUT, EPI, HbFull>(st, p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -830,7 +868,6 @@ extern "C" int vb_linear_bf16(void* stream, const vb_linear_bf16_args* a) {
     p.C = a->C; p.ldc = a->ldc; p.C32 = a->C32; p.ldc32 = a->ldc32;
     p.D = a->act_grad; p.ldd = a->ldg;
     p.tiles_n = p.N / HB_BN;
-    p.tiles = ((p.M + HB_BM - 1) / HB_BM) * p.tiles_n;
     p.drop_p = a->dropout_p;
     p.drop_scale = drop ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
     p.seed = a->seed;
