@@ -497,6 +497,17 @@ def main():
                         "batch": pb, "tokens": T, "regions": R, "gemm_family_tflops": round(tf, 1),
                         "gemm_frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "model_tflops": round(mtf, 1),
                         "note": "bert_large_6layer_6conect.json forward (VILBertForVLTasks, eval, all heads), one GPU"}
+            # the same forward in the MX inference mode (BASELINE configs[4] on configs[3]'s model); at the task shape the 101-key
+            # attention rows run on the key-tiled bf16 kernel, the 24-token text rows on the MX attention kernel
+            _native.set_gemm_mode("mxfp8")
+            try:
+                dt8 = timed(f, 2, n)
+            finally:
+                _native.set_gemm_mode("f32")
+            out[tag + "_mxfp8"] = {"value": round(pb * n / dt8, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt8 / n, 3),
+                                   "steps": n, "batch": pb, "tokens": T, "regions": R, "speedup_vs_fp32": round(dt / dt8, 2),
+                                   "model_tflops": round(pb * n / dt8 * tot / 1e12, 1), "dtype": "mxfp8 linears, bf16 attention",
+                                   "note": "the same forward with set_gemm_mode('mxfp8')"}
         del net
         torch.cuda.empty_cache()
         with torch.device(device):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 15
+#define VB_ABI_VERSION 16
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -236,9 +236,14 @@ int vb_linear_fwd_fp8(void* stream, const vb_linear_fp8_args* a);
  * the E8M0 bytes of row r's blocks 4 kt .. 4 kt + 3 (byte b = block 4 kt + b; value 2^(byte - 127); the smallest power of
  * two with amax_block / scale <= 448, byte 0 for an all-zero block). scale_rows >= rows is the row stride of a scale plane.
  *
- * vb_quantize_rows_mx: fp32 rows -> that format (weights: once per optimizer step; activations no producer quantises). */
+ * vb_quantize_rows_mx: fp32 rows -> that format (weights: once per optimizer step; activations no producer quantises).
+ * vb_quantize_rows_mx_bf16: the same for bfloat16 rows (ABI 16: the context of the key-tiled bf16 attention kernel, which
+ * serves the rows the MX attention kernel does not - more than 48 queries / keys, e.g. 101 regions; x 8-byte aligned). Bit-
+ * identical to vb_quantize_rows_mx on the rows widened to fp32. */
 int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const float* x, int64_t ldx, uint8_t* q, int64_t ldq,
                         uint32_t* scales, int64_t scale_rows);
+int vb_quantize_rows_mx_bf16(void* stream, int64_t rows, int32_t K, const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq,
+                             uint32_t* scales, int64_t scale_rows);
 
 /* nn.Linear forward on MX operands: v = act(A W^T + bias) (+ residual), A [M][K] and W [N][K] in the format above,
  * K % 128 == 0, N % 128 == 0; a_srows >= M rounded up to 256, w_srows >= N (both % 4 == 0; the kernel fetches the scale

@@ -33,7 +33,7 @@ def test_header_declares_the_expected_entry_points():
         "vb_image_embed_ln_fwd", "vb_additive_mask", "vb_attention_fwd"] + EXTRA_DECLS)
 
 
-EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_quantize_rows_mx", "vb_linear_fwd_mx", "vb_layernorm_fwd_mx", "vb_attention_fwd_mx", "vb_layernorm_fwd_mx16", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
+EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fwd", "vb_kl_bwd", "vb_adamw_step", "vb_set_gemm_mode", "vb_set_gemm_tile", "vb_set_gemm_v4", "vb_set_deterministic", "vb_deterministic_fallbacks", "vb_set_seed_epoch", "vb_bump_counter", "vb_linear_bwd_input", "vb_linear_bwd_weight", "vb_quantize_rows_fp8", "vb_linear_fwd_fp8", "vb_layernorm_fwd_fp8", "vb_quantize_rows_mx", "vb_quantize_rows_mx_bf16", "vb_linear_fwd_mx", "vb_layernorm_fwd_mx", "vb_attention_fwd_mx", "vb_layernorm_fwd_mx16", "vb_act_bwd", "vb_dropout", "vb_layernorm_bwd", "vb_layernorm_bwd_drop",
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd",
                # round 5: the bf16 training path (csrc/gemm_bf16.hip, rowops16.hip)
                "vb_attention_fwd_bf16", "vb_attention_bwd_bf16", "vb_linear_bf16", "vb_wgrad_bf16", "vb_colsum_bf16_workspace", "vb_colsum_bf16", "vb_weight_shadow_bf16", "vb_weight_shadow_multi",
@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 15
+    assert lib.vb_abi_version() == 16
     prev = native.set_gemm_mode("bf16x6")
     assert native.set_gemm_mode(prev) == "bf16x6" and native.set_gemm_mode(prev) == prev
     assert lib.vb_error_string(0) == b"ok"
@@ -90,7 +90,8 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.vb_attention_bwd(None, None, None) == -1
     assert lib.vb_linear_bwd_input(None, None) == -1 and lib.vb_linear_bwd_weight(None, None) == -1
     assert lib.vb_concap_finish_batch(None, None) == -1
-    assert lib.vb_linear_fwd_mx(None, None) == -1 and lib.vb_quantize_rows_mx(None, 0, 0, None, 0, None, 0, None, 0) == -1
+    assert lib.vb_linear_fwd_mx(None, None) == -1 and lib.vb_quantize_rows_mx(None, 0, 0, None, 0, None, 0, None, 0) == -1 \
+        and lib.vb_quantize_rows_mx_bf16(None, 0, 0, None, 0, None, 0, None, 0) == -1
     assert lib.vb_xent_fwd(None, 1, 0, None, 0, None, -1, None, None, None, None) == -1
     assert lib.vb_layernorm_bwd_workspace(16, 768) == 4 * 2 * 768
     assert lib.vb_layernorm_bwd_workspace(17, 768) == 8 * 2 * 768

@@ -391,3 +391,71 @@ def test_ragged_heads_run_on_a_zero_padded_weight_copy(mx_mode, M, N, K):
     assert (np.abs(y.cpu().numpy().astype(np.float64) - want) <= 1e-4 * mag).all()
     exact = x.double() @ w.double().t() + b.double()
     assert ((y.cpu().double() - exact).norm() / exact.norm()).item() <= 0.06
+
+
+@pytest.mark.parametrize("rows,K", [(7, 768), (130, 1024), (300, 640), (33, 2048)])
+def test_mx_quantiser_of_bfloat16_rows_is_the_fp32_quantiser_on_the_widened_rows(rows, K):
+    from vilbert import ops
+    x = _blocky(rows, K, seed=rows + 1).to(torch.bfloat16)
+    x[min(3, rows - 1)] = 0
+    m = ops.quantize_rows_mx(x.to(DEV))
+    q_ref, b_ref = F.mx_quantize(x.float().numpy())
+    assert np.array_equal(m.q.cpu().numpy(), q_ref), "%d codes differ" % int((m.q.cpu().numpy() != q_ref).sum())
+    assert np.array_equal(F.mx_words_to_bytes(_words(m), rows), b_ref)
+    view = x.to(DEV)[:, 128:384]          # a column slice: row-strided input
+    mv = ops.quantize_rows_mx(view)
+    qv, bv = F.mx_quantize(x[:, 128:384].float().numpy())
+    assert np.array_equal(mv.q.cpu().numpy(), qv) and np.array_equal(F.mx_words_to_bytes(_words(mv), rows), bv)
+
+
+@pytest.mark.parametrize("n_tok,n_reg", [(23, 101), (20, 200)])
+def test_mx_model_at_the_task_shapes_runs_its_attention_on_the_bf16_kernel(mx_mode, monkeypatch, n_tok, n_reg):
+    """vilbert_tasks.yml shapes (VQA: 23 tokens x 101 regions; Visual7w: 20 x 200) in the MX inference mode: rows beyond the MX
+    attention kernel's 48 go to the key-tiled bf16 kernel - never to the fp32 one - and the outputs stay within the MX mode's
+    drift of the fp32 kernels (which the oracle pins at 1e-4)."""
+    from oracle import synth
+    from vilbert import _native, ops, ops16
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    cfg.update(v_target_size=1601)
+    sd = synth.make_state_dict(cfg, "vltasks", seed=21)
+    net = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=3129)
+    net.load_state_dict(sd)
+    net = net.eval().to(DEV)
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    ids = torch.randint(0, cfg["vocab_size"], (B, n_tok), generator=g)
+    feat = torch.rand(B, n_reg, cfg["v_feature_size"], generator=g) * 2.0
+    loc = torch.rand(B, n_reg, 5, generator=g)
+    tmask = torch.ones(B, n_tok, dtype=torch.long)
+    tmask[1, n_tok - 5:] = 0                                   # padded tokens / regions, as the task loaders produce them
+    imask = torch.ones(B, n_reg, dtype=torch.long)
+    imask[2, n_reg - 30:] = 0
+    args = helpers.to_device((ids, feat, loc, torch.zeros(B, n_tok, dtype=torch.long), tmask, imask), DEV)
+    calls = {"mx": 0, "bf16": 0, "f32": 0}
+    real = {"mx": ops.attention_fwd_mx, "bf16": ops16.attention_fwd, "f32": ops.attention_fwd}
+    monkeypatch.setattr(ops, "attention_fwd_mx", lambda *a, **k: (calls.__setitem__("mx", calls["mx"] + 1), real["mx"](*a, **k))[1])
+    monkeypatch.setattr(ops16, "attention_fwd", lambda *a, **k: (calls.__setitem__("bf16", calls["bf16"] + 1), real["bf16"](*a, **k))[1])
+    monkeypatch.setattr(ops, "attention_fwd", lambda *a, **k: (calls.__setitem__("f32", calls["f32"] + 1), real["f32"](*a, **k))[1])
+    with torch.no_grad():
+        got = net(*args)
+    # text self-attention (23 / 20 rows): MX kernel; image self-attention and both directions of the connection layers: bf16
+    assert calls["f32"] == 0 and calls["mx"] >= 2 and calls["bf16"] >= 2 + 2 * 2, calls
+    prev = _native.set_gemm_mode("f32")
+    try:
+        with torch.no_grad():
+            want = net(*args)
+    finally:
+        _native.set_gemm_mode(prev)
+    names = ["vil_prediction", "vil_prediction_gqa", "vil_logit", "vil_binary_prediction", "vil_tri_prediction", "vision_prediction",
+             "vision_logit", "linguisic_prediction", "linguisic_logit"]
+    for n, a, b in zip(names, got, want):
+        if not torch.is_tensor(a) or n == "vision_logit":
+            continue
+        a, b = a.double().cpu(), b.double().cpu()
+        assert torch.isfinite(a).all(), n
+        rel = ((a - b).abs().max() / b.abs().max()).item()
+        l2 = ((a - b).norm() / b.norm()).item()
+        print("mxfp8 mode at %d tokens x %d regions, %s: max err %.3f of the output range, relative L2 %.3f" % (n_tok, n_reg, n, rel, l2))
+        bound = 0.25 if b.numel() > 16 else 0.45
+        assert rel <= bound and l2 <= bound, (n, rel, l2)

@@ -38,7 +38,9 @@ def test_every_encoder_linear_of_the_north_star_configs_is_mx_eligible(mx, name)
             assert ops.mx_eligible(K, N, None), (K, N)
         assert ops.mx_eligible(H, I, "gelu") and not ops.mx_eligible(H, Hb, "relu")          # poolers: ReLU -> row-scaled kernel
         assert ops.mx_attention_ok(36, 37, H // c["num_attention_heads"]) and ops.mx_attention_ok(37, 37, Hv // c["v_num_attention_heads"])
-        assert not ops.mx_attention_ok(36, 101, 128) and not ops.mx_attention_ok(36, 36, 32)
+        # the task shapes (101 / 200 regions) stay on bf16 q | k | v too - on the key-tiled bf16 kernel; past MAX_KEYS nothing does
+        assert ops.mx_attention_ok(23, 101, 128) and ops.mx_attention_ok(200, 20, 64) and not ops.mx_attention_ok(36, 36, 32)
+        assert not ops.mx_attention_ok(36, ops.MAX_KEYS + 1, 64)
         assert not ops.mx_attention_ok(36, 36, 64, drop_p=0.1) and not ops.mx_attention_ok(36, 36, 64, other=True)
         assert ops.mx_stream_bf16()
     assert not ops.mx_eligible(H, H, None) and not ops.mx_attention_ok(36, 36, 64) and not ops.mx_stream_bf16()   # grad mode on

@@ -44,10 +44,8 @@ constexpr int HB_LW = 2;
 constexpr int HB_MFMA_WAVES = 8, HB_THREADS = 64 * (HB_MFMA_WAVES + 2 * HB_LW);
 
 // Block shapes of the NT kernel. HbFull: the geometry above, ONE block per CU. HbHalf: 128 x 128 tiles, 4 MFMA waves (2 x 2) + one
-// loader wave per operand, a 2-stage ring of 32 KiB stages = 64 KiB, so that TWO independent blocks share a CU: while one block
-// is in its epilogue - during which the full-size kernel's CU computes nothing (section 4.5 of DESIGN.md: 30 - 50 % of a
-// short-K multi-round launch) - the other one's MFMAs keep the matrix pipe busy, and each block's single tile of DMA lookahead
-// is covered by its neighbour as well.
+// loader wave per operand, a 2-stage ring of 32 KiB stages = 64 KiB, so that TWO independent blocks share a CU. Built to hide
+// one block's epilogue under the other's MFMAs; measured, that only pays for SMALL launches (see launch_hb).
 template <int BM_, int S_, int LW_>
 struct HbCfg {
     static constexpr int BM = BM_, S = S_, LW = LW_;
@@ -404,13 +402,15 @@ int launch_hb_cfg(hipStream_t st, HbP p) {
 }
 
 // VB_BF16_HALF: 0 = always the full-size block, 2 = always two half-size blocks per CU, 1 (default) = the half-size blocks for
-// launches whose 256-row tiles need more than one round of the 256 CUs AND have a short contraction (K <= 1024) - the launches
-// whose epilogue is not hidden by anything (profiles/r05_bf16_lab_ablations.txt)
+// launches of at most 128 full-size tiles (the per-GPU batch 64 shapes: 80 tiles on 256 CUs become 160 blocks - 23.5 -> 16.6 us
+// at 2368 x 1024 x 1024). Everywhere else the half-size block LOSES (profiles/r05_bf16_half_blocks.txt): a 128 x 128 tile
+// reads a third more operand bytes per FLOP through L2 / LDS-DMA, and the main loop alone falls from ~1.0 PF to 0.62 - 0.74 PF -
+// more than the overlapped epilogues win back (q|k|v forward 44.8 -> 67.7 us).
 template <int OUT, int EPI>
 int launch_hb(hipStream_t st, const HbP& p) {
     static const int half = [] { const char* e = getenv("VB_BF16_HALF"); return e ? atoi(e) : 1; }();
     const int tiles_full = ((p.M + 255) / 256) * p.tiles_n;
-    const bool use_half = half == 2 || (half == 1 && tiles_full > 256 && p.K <= 1024);
+    const bool use_half = half == 2 || (half == 1 && tiles_full <= 128);
     return use_half ? launch_hb_cfg<OUT, EPI, HbHalf>(st, p) : launch_hb_cfg<OUT, EPI, HbFull>(st, p);
 }
 

@@ -51,20 +51,28 @@ using namespace vbgemm;
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int NV>
-__global__ __launch_bounds__(256) void quant_rows_mx_kernel(long rows, int K, const float* __restrict__ x, long ldx,
+// four consecutive elements of an fp32 or a bfloat16 row as f32x4
+__device__ __forceinline__ f32x4 mx_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 mx_ld4(const unsigned short* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                 __uint_as_float(t.y & 0xffff0000u)};
+}
+
+template <int NV, class IN>
+__global__ __launch_bounds__(256) void quant_rows_mx_kernel(long rows, int K, const IN* __restrict__ x, long ldx,
                                                             unsigned char* __restrict__ q, long ldq,
                                                             unsigned* __restrict__ sc, long sc_rows) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* __restrict__ src = x + row * ldx;
+    const IN* __restrict__ src = x + row * ldx;
     unsigned char* __restrict__ qrow = q + row * ldq;
     const int nkt = K >> 7;
     if (NV > 0) {
         f32x4 reg[NV > 0 ? NV : 1];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const f32x4*>(src + 256 * i + 4 * lane);
+        for (int i = 0; i < NV; ++i) reg[i] = mx_ld4(src + 256 * i + 4 * lane);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int kt = 2 * i + (lane >> 5);
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256) void quant_rows_mx_kernel(long rows, int K, co
             const int col = c0 + 4 * lane;
             const bool ok = col < K;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(src + col);
+            if (ok) v = mx_ld4(src + col);
             const int kt = (c0 >> 7) + (lane >> 5);
             mx_quant_chunk(v, ok, lane, kt, nkt, reinterpret_cast<unsigned*>(qrow + (ok ? col : 0)),
                            sc + (long)(kt < nkt ? kt : 0) * sc_rows + row);
@@ -541,15 +549,19 @@ int launch_mx(hipStream_t st, const MxP& p) {
 
 }  // namespace
 
-extern "C" int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const float* x, int64_t ldx, uint8_t* q, int64_t ldq,
-                                   uint32_t* scales, int64_t scale_rows) {
+namespace {
+template <class IN>
+int quantize_rows_mx(void* stream, int64_t rows, int32_t K, const IN* x, int64_t ldx, uint8_t* q, int64_t ldq, uint32_t* scales,
+                     int64_t scale_rows) {
     if (x == nullptr || q == nullptr || scales == nullptr || rows <= 0 || K <= 0) return VB_E_BADARG;
-    if (K % 128 != 0 || ldx % 4 != 0 || ldq % 4 != 0 || ldq < K || ldx < K || scale_rows < rows || !vb_aligned16(x) ||
-        (reinterpret_cast<uintptr_t>(q) & 3u) != 0 || (reinterpret_cast<uintptr_t>(scales) & 3u) != 0)
+    // (rows of 4 elements per lane: 16-byte loads of fp32, 8-byte loads of bfloat16)
+    if (K % 128 != 0 || ldx % 4 != 0 || ldq % 4 != 0 || ldq < K || ldx < K || scale_rows < rows ||
+        (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(IN) - 1)) != 0 || (reinterpret_cast<uintptr_t>(q) & 3u) != 0 ||
+        (reinterpret_cast<uintptr_t>(scales) & 3u) != 0)
         return VB_E_ALIGN;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define VB_QUANT(NV) hipLaunchKernelGGL(quant_rows_mx_kernel<NV>, grid, block, 0, st, (long)rows, (int)K, x, (long)ldx, q, (long)ldq, scales, (long)scale_rows)
+#define VB_QUANT(NV) hipLaunchKernelGGL((quant_rows_mx_kernel<NV, IN>), grid, block, 0, st, (long)rows, (int)K, x, (long)ldx, q, (long)ldq, scales, (long)scale_rows)
     switch (K) {
         case 768: VB_QUANT(3); break;
         case 1024: VB_QUANT(4); break;
@@ -560,6 +572,17 @@ extern "C" int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const 
 #undef VB_QUANT
     VB_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+extern "C" int vb_quantize_rows_mx(void* stream, int64_t rows, int32_t K, const float* x, int64_t ldx, uint8_t* q, int64_t ldq,
+                                   uint32_t* scales, int64_t scale_rows) {
+    return quantize_rows_mx<float>(stream, rows, K, x, ldx, q, ldq, scales, scale_rows);
+}
+
+extern "C" int vb_quantize_rows_mx_bf16(void* stream, int64_t rows, int32_t K, const uint16_t* x, int64_t ldx, uint8_t* q,
+                                        int64_t ldq, uint32_t* scales, int64_t scale_rows) {
+    return quantize_rows_mx<unsigned short>(stream, rows, K, x, ldx, q, ldq, scales, scale_rows);
 }
 
 extern "C" int vb_linear_fwd_mx(void* stream, const vb_linear_mx_args* a) {

@@ -222,6 +222,7 @@ SIGNATURES = {
     "vb_linear_fwd_fp8": (ctypes.c_int, [_P, ctypes.POINTER(LinearFp8Args)]),
     "vb_layernorm_fwd_fp8": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P]),
     "vb_quantize_rows_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _I64]),
+    "vb_quantize_rows_mx_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64, _P, _I64]),
     "vb_linear_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(LinearMxArgs)]),
     "vb_layernorm_fwd_mx": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _F32, _P, _P, _I64, _P, _I64]),
     "vb_attention_fwd_mx": (ctypes.c_int, [_P, ctypes.POINTER(AttentionMxArgs)]),
@@ -275,7 +276,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 15:
+        if handle.vb_abi_version() != 16:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") in ("fp8", "mxfp8"):

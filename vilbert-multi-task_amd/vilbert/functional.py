@@ -141,7 +141,7 @@ def self_attention(qkv, mask_add, heads, drop_p=0.0, want_probs=False):
         return out, (probs if want_probs else None)
     H = qkv.shape[-1] // 3
     if qkv.dtype == torch.bfloat16:     # MX inference mode: bf16 projection in, MX context out (ops.mx_attention_ok held)
-        return ops.attention_fwd_mx(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads), None
+        return ops.attention_fwd_mx_any(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads), None
     seed = A.next_seed() if drop_p > 0.0 else 0
     out, probs, _ = ops.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads,
                                       want_probs, False, drop_p, seed)
@@ -170,8 +170,8 @@ def bi_attention(qkv1, qkv2, mask1, mask2, heads, p1=0.0, p2=0.0, want_probs=Fal
         return c1, c2, (pr1 if want_probs else None), (pr2 if want_probs else None)
     H = qkv1.shape[-1] // 3
     if qkv1.dtype == torch.bfloat16 and qkv2.dtype == torch.bfloat16:
-        c1 = ops.attention_fwd_mx(qkv2[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:], mask1, heads)
-        c2 = ops.attention_fwd_mx(qkv1[..., :H], qkv2[..., H:2 * H], qkv2[..., 2 * H:], mask2, heads)
+        c1 = ops.attention_fwd_mx_any(qkv2[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:], mask1, heads)
+        c2 = ops.attention_fwd_mx_any(qkv1[..., :H], qkv2[..., H:2 * H], qkv2[..., 2 * H:], mask2, heads)
         return c1, c2, None, None
     s1 = A.next_seed() if p1 > 0.0 else 0
     s2 = A.next_seed() if p2 > 0.0 else 0

@@ -216,11 +216,17 @@ class MxRows(object):
 
 
 def quantize_rows_mx(x2, lead=None, out=None):
-    """x2 [rows, K] fp32 (row stride allowed, K % 128 == 0) -> MxRows."""
+    """x2 [rows, K] fp32 or bfloat16 (row stride allowed, K % 128 == 0) -> MxRows."""
     rows, K = x2.shape
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
     m = out if out is not None else MxRows(rows, K, x2.device, lead if lead is not None else (rows,))
+    if x2.dtype == torch.bfloat16:
+        if not x2.is_cuda:
+            raise RuntimeError("mx quantise input: expected a tensor on a HIP device - no CPU fallback")
+        N.check(N.lib().vb_quantize_rows_mx_bf16(N.stream_ptr(), rows, K, x2.data_ptr(), x2.stride(0), m.q.data_ptr(),
+                                                 m.q.stride(0), m.s.data_ptr(), m.srows), "vb_quantize_rows_mx_bf16")
+        return m
     N.check(N.lib().vb_quantize_rows_mx(N.stream_ptr(), rows, K, N.dev_f32(x2, "mx quantise input"), x2.stride(0),
                                         m.q.data_ptr(), m.q.stride(0), m.s.data_ptr(), m.srows), "vb_quantize_rows_mx")
     return m
@@ -305,8 +311,7 @@ def _mx_of(x, x2, M, K, lead):
     tag = getattr(x, "_vb_mx", None)
     if tag is not None and tag[1] == x._version and tag[0].rows == M and tag[0].K == K and x.is_contiguous():
         return tag[0]
-    if x2.dtype != torch.float32:                        # a bf16 tensor that lost its codes (expand / index of a hidden state)
-        x2 = x2.float()
+    # (a bf16 tensor without codes: the context of the key-tiled bf16 attention, an expand / index of a hidden state)
     return quantize_rows_mx(x2, lead)
 
 
@@ -807,9 +812,20 @@ MX_ATTN_MAX_ROWS = 48
 
 
 def mx_attention_ok(n_q, n_k, head_dim, drop_p=0.0, other=False):
-    """The MX path's attention kernel (csrc/attention_mx.hip: bf16 q | k | v in, MX context out) serves this call."""
-    return (N.mx_enabled() and not torch.is_grad_enabled() and n_q <= MX_ATTN_MAX_ROWS and n_k <= MX_ATTN_MAX_ROWS
+    """The MX path's attention serves this call on a bf16 q | k | v projection: up to 48 queries / keys on
+    csrc/attention_mx.hip (MX context out), longer rows - the task shapes: 101 / 200 regions, up to MAX_KEYS - on the
+    key-tiled bf16-MFMA kernel of the bf16 training path (csrc/attention.hip built with bf16 tensors), whose bf16 context
+    the output projection quantises (vb_quantize_rows_mx_bf16)."""
+    return (N.mx_enabled() and not torch.is_grad_enabled() and n_q <= MAX_KEYS and n_k <= MAX_KEYS
             and head_dim in (64, 128) and drop_p == 0.0 and not other)
+
+
+def attention_fwd_mx_any(q, k, v, mask_add, heads):
+    """attention_fwd_mx where its kernel fits (MxRows), else the bf16 kernel (bfloat16 context tensor)."""
+    if q.shape[1] <= MX_ATTN_MAX_ROWS and k.shape[1] <= MX_ATTN_MAX_ROWS:
+        return attention_fwd_mx(q, k, v, mask_add, heads)
+    from . import ops16
+    return ops16.attention_fwd(q, k, v, mask_add, heads, False, 0.0, 0)[0]
 
 
 def attention_fwd_mx(q, k, v, mask_add, heads):
