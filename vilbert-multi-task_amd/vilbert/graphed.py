@@ -51,7 +51,16 @@ class GraphedTrainStep(object):
     """``with GraphedTrainStep(model, opt, batch) as step: ...`` or ``step.close()`` when done; a step that is simply
     dropped is cleaned up by its finaliser."""
 
-    def __init__(self, model, optimizer, example_inputs, loss_fn=None, label_capacity=0.25, warmup=3, check_every=1):
+    def __init__(self, model, optimizer, example_inputs, loss_fn=None, label_capacity=0.25, warmup=3, check_every=1,
+                 branches="chain"):
+        """branches: "chain" (default) = the step is captured as ONE chain of kernel nodes - the text || image fork of the
+        encoder runs sequentially inside the capture; "fork" = the fork becomes parallel branches of the graph. Measured at
+        batch 64 (profiles/r05_b64_graph_chain.txt): the chain replays in 18.9 ms (bf16 mode; eager 23.7 ms, host-bound) and
+        37.3 ms (fp32), the forked graph in 26.7 / 42.0 ms - this HIP runtime serialises cross-branch edges at replay at a cost
+        that exceeds what the overlap buys (the same effect GraphedForward(branches="auto") measures per instance)."""
+        if branches not in ("chain", "fork"):
+            raise ValueError("branches: chain | fork")
+        self.branches = branches
         self.model, self.opt = model, optimizer
         self.loss_fn = loss_fn or _default_loss
         base = model.module if hasattr(model, "module") else model
@@ -84,7 +93,10 @@ class GraphedTrainStep(object):
         # (the weight-gradient side streams stay out of the graph: every cross-stream edge costs at replay - measured
         # 1,645 samples/s with them vs 1,730 without at batch 64 - and a replay has no launch gaps for them to fill)
         from . import autograd_ops as _A
+        from . import vilbert as _V
         prev_ws = _A.set_wgrad_stream(False)
+        prev_fork = _V._TWO_STREAMS_IN_GRAPH
+        _V._TWO_STREAMS_IN_GRAPH = prev_fork and branches == "fork"
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -102,6 +114,7 @@ class GraphedTrainStep(object):
             self._det_workspace = N.deterministic_workspace(dev)
         finally:
             _A.set_wgrad_stream(prev_ws)
+            _V._TWO_STREAMS_IN_GRAPH = prev_fork
         with torch.no_grad():
             i = 0
             for g in optimizer.param_groups:
