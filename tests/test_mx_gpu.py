@@ -459,3 +459,25 @@ def test_mx_model_at_the_task_shapes_runs_its_attention_on_the_bf16_kernel(mx_mo
         print("mxfp8 mode at %d tokens x %d regions, %s: max err %.3f of the output range, relative L2 %.3f" % (n_tok, n_reg, n, rel, l2))
         bound = 0.25 if b.numel() > 16 else 0.45
         assert rel <= bound and l2 <= bound, (n, rel, l2)
+
+
+@pytest.mark.parametrize("rows,cols", [(18435, 768), (16390, 1024), (20001, 256)])
+def test_bf16_stream_layernorm_four_rows_per_wave_is_bit_identical(mx_mode, rows, cols):
+    """Past 16,384 rows (batch 512: 18,432 token rows) the launcher gives every wave four rows instead of two, so that the
+    blocks still fit the chip in one round; same arithmetic per row - y, codes and scale bytes must not change by a bit.
+    Reference: the same rows through two launches of at most 16,384 rows (the two-row form)."""
+    from vilbert import ops
+    g_ = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cols, generator=g_) * 2).to(torch.bfloat16).to(DEV)
+    g, b = (1 + 0.1 * torch.randn(cols, generator=g_)).to(DEV), (0.1 * torch.randn(cols, generator=g_)).to(DEV)
+    with torch.no_grad():
+        y, _, _ = ops.layernorm_fwd(x, g, b, 1e-12)
+        cut = 16384
+        ya, _, _ = ops.layernorm_fwd(x[:cut].contiguous(), g, b, 1e-12)
+        yb, _, _ = ops.layernorm_fwd(x[cut:].contiguous(), g, b, 1e-12)
+    m, ma, mb = y._vb_mx[0], ya._vb_mx[0], yb._vb_mx[0]
+    assert torch.equal(y[:cut], ya) and torch.equal(y[cut:], yb)
+    assert torch.equal(m.q[:cut], ma.q) and torch.equal(m.q[cut:], mb.q)
+    got = F.mx_words_to_bytes(_words(m), rows)
+    assert np.array_equal(got[:cut], F.mx_words_to_bytes(_words(ma), cut))
+    assert np.array_equal(got[cut:], F.mx_words_to_bytes(_words(mb), rows - cut))

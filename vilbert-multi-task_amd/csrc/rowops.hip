@@ -308,19 +308,22 @@ namespace {
 // LayerNorm of the MX path's bf16 residual stream: bf16 row in, bf16 row + MX codes out (lane = 4 consecutive columns of
 // every 256-column chunk, as layernorm_kernel). A wave owns TWO rows and runs their dependent chains (load -> sum -> wave
 // reduction -> squared deviations -> wave reduction -> codes) side by side: with one row per wave the launch was bound by
-// that chain's latency times the number of block rounds (29.5 us for 70 MB at 18,432 x 768), not by HBM.
-constexpr int LN16_RPW = 2;
-
-__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+// that chain's latency times the number of block rounds (29.5 us for 70 MB at 18,432 x 768), not by HBM. LN16_RPW = 2 or 4:
+// the launcher picks 4 when two rows per wave would need more blocks than fit the chip at once (8 per CU) - at batch 512
+// (18,432 rows) the 2,304 blocks of the two-row form ran as one full round plus a 12 % tail round of the same latency.
+template <int R>
+__device__ __forceinline__ void wave_sum_n(float (&a)[R]) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const float ta = __shfl_xor(a, off, 64), tb = __shfl_xor(b, off, 64);
-        a += ta;
-        b += tb;
+        float t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) t[r] = __shfl_xor(a[r], off, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] += t[r];
     }
 }
 
-template <int NV>
+template <int NV, int LN16_RPW>
 __global__ __launch_bounds__(256) void layernorm16_mx_kernel(long rows, int n_cols, const unsigned short* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, unsigned short* __restrict__ y,
@@ -329,41 +332,61 @@ __global__ __launch_bounds__(256) void layernorm16_mx_kernel(long rows, int n_co
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6)) * LN16_RPW;
     if (row0 >= rows) return;
-    const bool two = row0 + 1 < rows;                   // (wave-uniform) the second row exists
-    const long rrow[LN16_RPW] = {row0, two ? row0 + 1 : row0};
-    f32x4 v[LN16_RPW][NV];
-    float s[LN16_RPW] = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < LN16_RPW; ++r)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int col = (i * 64 + lane) * 4;
-            v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (col < n_cols) {
-                const uint2 w = *reinterpret_cast<const uint2*>(x + rrow[r] * n_cols + col);
-                v[r][i] = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
-                                __uint_as_float(w.y & 0xffff0000u)};
-            }
-        }
-#pragma unroll
-    for (int r = 0; r < LN16_RPW; ++r)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);   // (columns past n_cols hold 0)
-    wave_sum2(s[0], s[1]);
-    float var[LN16_RPW] = {0.f, 0.f};
+    long rrow[LN16_RPW];                                // rows past the end: row0 again, every store masked
+    bool have[LN16_RPW];                                // (wave-uniform)
 #pragma unroll
     for (int r = 0; r < LN16_RPW; ++r) {
-        const float mean = s[r] / (float)n_cols;
+        have[r] = row0 + r < rows;
+        rrow[r] = have[r] ? row0 + r : row0;
+    }
+    // the rows stay PACKED in registers (2 per 4 values) and are widened wherever they are used: four rows of 1,024 columns
+    // in 32 registers keep the occupancy at 8 waves per SIMD (as fp32 they took 64 and the kernel 112)
+    uint2 w[LN16_RPW][NV];
+    auto wide = [](const uint2 t) {
+        return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                     __uint_as_float(t.y & 0xffff0000u)};
+    };
+#pragma unroll
+    for (int r = 0; r < LN16_RPW; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * 4;
+            w[r][i] = uint2{0u, 0u};
+            if (col < n_cols) w[r][i] = *reinterpret_cast<const uint2*>(x + rrow[r] * n_cols + col);
+        }
+    float mean[LN16_RPW], var[LN16_RPW];
+#pragma unroll
+    for (int r = 0; r < LN16_RPW; ++r) {
+        mean[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 v = wide(w[r][i]);
+            mean[r] += (v[0] + v[1]) + (v[2] + v[3]);   // (columns past n_cols hold 0)
+        }
+    }
+    wave_sum_n(mean);
+    auto opaque = [&]() {   // the compiler must not keep the widened copies of one phase for the next (that is the 64 registers)
+#pragma unroll
+        for (int r = 0; r < LN16_RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(w[r][i].x), "+v"(w[r][i].y));
+    };
+    opaque();
+#pragma unroll
+    for (int r = 0; r < LN16_RPW; ++r) {
+        mean[r] /= (float)n_cols;
+        var[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (i * 64 + lane) * 4;
             if (col < n_cols) {
-                v[r][i] -= mean;
-                var[r] += (v[r][i][0] * v[r][i][0] + v[r][i][1] * v[r][i][1]) + (v[r][i][2] * v[r][i][2] + v[r][i][3] * v[r][i][3]);
+                const f32x4 d = wide(w[r][i]) - mean[r];
+                var[r] += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
         }
     }
-    wave_sum2(var[0], var[1]);
+    wave_sum_n(var);
+    opaque();
     const int nkt = n_cols >> 7;
     auto bf = [](float f) -> unsigned { const unsigned u = __float_as_uint(f); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
 #pragma unroll
@@ -379,14 +402,14 @@ __global__ __launch_bounds__(256) void layernorm16_mx_kernel(long rows, int n_co
 #pragma unroll
         for (int r = 0; r < LN16_RPW; ++r) {
             const float rstd = 1.0f / sqrtf(var[r] / (float)n_cols + eps);
-            const bool live = ok && (r == 0 || two);
-            if (ok) v[r][i] = g * (v[r][i] * rstd) + b;
+            const bool live = ok && have[r];
+            f32x4 v = wide(w[r][i]);
+            if (ok) v = g * ((v - mean[r]) * rstd) + b;
             if (live)
                 *reinterpret_cast<uint2*>(y + rrow[r] * n_cols + col) =
-                    uint2{bf(v[r][i][0]) | (bf(v[r][i][1]) << 16), bf(v[r][i][2]) | (bf(v[r][i][3]) << 16)};
-            // (the cross-lane steps inside run for every lane; the stores of the row that does not exist are masked)
-            mx_quant_chunk(v[r][i], live, lane, (r == 0 || two) ? kt : nkt, nkt,
-                           reinterpret_cast<unsigned*>(q + rrow[r] * ldq + (ok ? col : 0)),
+                    uint2{bf(v[0]) | (bf(v[1]) << 16), bf(v[2]) | (bf(v[3]) << 16)};
+            // (the cross-lane steps inside run for every lane; the stores of the rows that do not exist are masked)
+            mx_quant_chunk(v, live, lane, have[r] ? kt : nkt, nkt, reinterpret_cast<unsigned*>(q + rrow[r] * ldq + (ok ? col : 0)),
                            mxs + (long)(kt < nkt ? kt : 0) * mxs_rows + rrow[r]);
         }
     }
@@ -405,10 +428,23 @@ extern "C" int vb_layernorm_fwd_mx16(void* stream, int64_t rows, int32_t n_cols,
         (reinterpret_cast<uintptr_t>(scales) & 3u) != 0)
         return VB_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    constexpr int per_block = ROWS_PER_BLOCK * LN16_RPW;
-    dim3 grid((unsigned)((rows + per_block - 1) / per_block)), block(256);
-    VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm16_mx_kernel<NV>), grid, block, 0, st, (long)rows, n_cols, x, gamma,
-                                                      beta, eps, y, q, (long)ldq, scales, (long)scale_rows));
+    const dim3 block(256);
+    if ((rows + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK) <= 2048 || n_cols > 1024) {
+        const dim3 grid((unsigned)((rows + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK)));
+        VB_NV_DISPATCH(nv_for(n_cols), hipLaunchKernelGGL((layernorm16_mx_kernel<NV, 2>), grid, block, 0, st, (long)rows, n_cols, x,
+                                                          gamma, beta, eps, y, q, (long)ldq, scales, (long)scale_rows));
+    } else {   // (rows of at most 1,024 columns: 4 x 4 float4 registers per lane)
+        const dim3 grid((unsigned)((rows + 4 * ROWS_PER_BLOCK - 1) / (4 * ROWS_PER_BLOCK)));
+        switch (nv_for(n_cols)) {
+#define VB_LN16_4(NV) hipLaunchKernelGGL((layernorm16_mx_kernel<NV, 4>), grid, block, 0, st, (long)rows, n_cols, x, gamma, beta, eps, y, \
+                                         q, (long)ldq, scales, (long)scale_rows)
+            case 1: VB_LN16_4(1); break;
+            case 2: VB_LN16_4(2); break;
+            case 3: VB_LN16_4(3); break;
+            default: VB_LN16_4(4); break;
+#undef VB_LN16_4
+        }
+    }
     VB_LAUNCH_CHECK();
     return 0;
 }
