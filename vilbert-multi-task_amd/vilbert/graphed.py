@@ -52,12 +52,18 @@ class GraphedTrainStep(object):
     dropped is cleaned up by its finaliser."""
 
     def __init__(self, model, optimizer, example_inputs, loss_fn=None, label_capacity=0.25, warmup=3, check_every=1,
-                 branches="chain"):
-        """branches: "chain" (default) = the step is captured as ONE chain of kernel nodes - the text || image fork of the
-        encoder runs sequentially inside the capture; "fork" = the fork becomes parallel branches of the graph. Measured at
-        batch 64 (profiles/r05_b64_graph_chain.txt): the chain replays in 18.9 ms (bf16 mode; eager 23.7 ms, host-bound) and
-        37.3 ms (fp32), the forked graph in 26.7 / 42.0 ms - this HIP runtime serialises cross-branch edges at replay at a cost
-        that exceeds what the overlap buys (the same effect GraphedForward(branches="auto") measures per instance)."""
+                 branches=None):
+        """branches: "chain" = the step is captured as ONE chain of kernel nodes - the text || image fork of the encoder runs
+        sequentially inside the capture; "fork" = the fork becomes parallel branches of the graph; None (default) = "chain" in
+        the bf16 training mode, "fork" otherwise. Measured at batch 64 (profiles/r05_b64_graph_chain.txt): the chain replays in
+        18.9 ms (bf16 mode; eager 23.7 ms, host-bound; forked graph 26.7 ms) - this HIP runtime serialises cross-branch edges at
+        replay at a cost that exceeds what the overlap buys (the effect GraphedForward(branches="auto") measures per instance).
+        fp32: chain 37.3 / fork 42.0 / eager 32.0 ms - GPU-bound, a graph does not pay there. Known issue: the "chain" form of the
+        opt-in fp8 training mode ("fp8", "fp8+bf16") replays wrong losses from the third replay on once the process has freed
+        device memory before the capture (tools/dbg_graph_nan.py S5 / S6; fork, fp32 and bf16 chains are not affected) - those
+        modes therefore keep the forked form, which every round's suite has covered."""
+        if branches is None:
+            branches = "chain" if N.bf16_stream() else "fork"
         if branches not in ("chain", "fork"):
             raise ValueError("branches: chain | fork")
         self.branches = branches
