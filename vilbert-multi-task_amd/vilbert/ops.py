@@ -137,11 +137,14 @@ def _fp8_weights(weights, biases):
         for s, w in enumerate(weights):
             quantize_rows_fp8(w.detach(), q[s * seg_n:(s + 1) * seg_n], sc[s * seg_n:(s + 1) * seg_n])
         if biases is not None and all(b is not None for b in biases):
-            cat = biases[0].detach() if len(biases) == 1 else torch.cat([b.detach() for b in biases])
-            if bias is None or len(biases) == 1:
-                bias = cat
+            if len(biases) == 1:
+                bias = biases[0].detach()
+            elif bias is None:
+                bias = torch.cat([b.detach() for b in biases])
             else:
-                bias.copy_(cat)
+                # refresh in place: the concatenation kernel writes the cached buffer itself (no temporary + device-to-device
+                # copy, which inside a captured step is a memcpy node between two kernel nodes)
+                torch.cat([b.detach() for b in biases], out=bias)
         elif biases is not None and any(b is not None for b in biases):
             raise RuntimeError("linear (fp8): either every weight segment has a bias or none")
         else:
