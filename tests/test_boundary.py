@@ -145,3 +145,20 @@ def test_constructor_and_forward_signatures_equal_the_reference():
     assert checked >= 40
     for fn in ("from_dict", "from_json_file", "to_dict", "to_json_string"):
         assert str(inspect.signature(getattr(ours.BertConfig, fn))) == str(inspect.signature(getattr(ref.BertConfig, fn)))
+
+
+def test_half_switches_to_the_bf16_training_mode_and_keeps_fp32_master_weights():
+    """The reference's scripts call `model.half()` for reduced-precision training (train_concap.py:504-505) next to an
+    optimizer that keeps fp32 master weights; here that is the bf16 stream: the process switches mode, the parameters stay
+    fp32 (no kernel of the package takes fp16 parameters), the call returns the model like nn.Module.half()."""
+    from vilbert import _native
+    m = _build("pretraining", synth.tiny_config())
+    prev = _native.set_gemm_mode("f32")
+    try:
+        assert not _native.bf16_stream()
+        assert m.half() is m
+        assert _native.bf16_stream() and _native.set_gemm_mode("bf16") == "bf16"
+        assert all(p.dtype == torch.float32 for p in m.parameters())
+    finally:
+        _native.set_gemm_mode(prev)
+    assert not _native.bf16_stream() or prev == "bf16"

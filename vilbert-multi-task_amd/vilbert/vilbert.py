@@ -821,6 +821,17 @@ class BertPreTrainedModel(PreTrainedModel):
     def __init__(self, *inputs, **kwargs):
         super(BertPreTrainedModel, self).__init__(*inputs, **kwargs)
 
+    def half(self):
+        """What the reference's scripts call for reduced-precision training (`model.half()` next to apex's FP16_Optimizer,
+        which keeps fp32 master weights: train_concap.py:443-461,504-505; train_tasks.py:168-171). Here that mode is the bf16
+        stream of DESIGN.md section 4.5: activations, saved tensors and activation gradients become bfloat16, the parameters
+        STAY fp32 (they are the master weights; the kernels keep their own bf16 copies) - so this switches the process into
+        `_native.set_gemm_mode("bf16")` and returns the model unchanged, instead of casting parameters to fp16, which no
+        kernel of this package takes. `_native.set_gemm_mode("f32")` switches back."""
+        _native.set_gemm_mode("bf16")
+        logger.info("half(): bf16 training mode on (bfloat16 activations / gradients, fp32 master weights); parameters unchanged")
+        return self
+
     def init_weights(self, module):
         if isinstance(module, (nn.Linear, nn.Embedding)):
             module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
