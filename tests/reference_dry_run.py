@@ -147,7 +147,7 @@ class _ConcapLoader(object):
             yield tuple(torch.from_numpy(fin[k]) for k in order) + (list(range(self.batch_size)),)
 
 
-def run_concap(work):
+def run_concap(work, fp16=False):
     import torch
     observed = dict(forward_calls=0, optimizer_steps=0)
     (_observe_device_side if torch.cuda.is_available() else _mock_device_side)(observed)
@@ -162,15 +162,38 @@ def run_concap(work):
     sys.argv = [os.path.join(REF, "train_concap.py"), "--from_pretrained", "bert-base-uncased", "--bert_model", "bert-base-uncased",
                 "--config_file", "config/bert_base_2layer_2conect.json", "--train_batch_size", "4",
                 "--max_seq_length", "12", "--num_train_epochs", "1", "--output_dir", out, "--objective", "1",
-                "--num_workers", "0"]
+                "--num_workers", "0"] + (["--fp16"] if fp16 else [])
     import vilbert.vilbert as V
     real_from_pretrained = V.BertForMultiModalPreTraining.from_pretrained.__func__
+    if fp16:
+        real_half = V.BertPreTrainedModel.half
+
+        def half(self):
+            observed["half_called"] = True
+            return real_half(self)
+        V.BertPreTrainedModel.half = half
 
     def from_pretrained(cls, name, *a, **k):       # no checkpoint download here: random init, like `--from_pretrained ""`
         observed["from_pretrained"] = name
         k.pop("default_gpu", None)
         return cls(k.pop("config"), *a, **k)
     V.BertForMultiModalPreTraining.from_pretrained = classmethod(from_pretrained)
+    if fp16:
+        # The reference's own --fp16 branch cannot finish a step upstream either: train_concap.py:576 calls `warmup_linear`,
+        # a name the script never imports. Getting THAT far - apex.optimizers.FusedAdam / FP16_Optimizer constructed
+        # (:443-461), WarmupLinearSchedule around it, model.half() (:504-505), a forward and `optimizer.backward(loss)`
+        # (:570-571) - is what the drop-in has to provide.
+        import traceback
+        try:
+            runpy.run_path(sys.argv[0], run_name="__main__")
+            observed["died_with"] = None
+        except NameError as exc:
+            tb = traceback.extract_tb(exc.__traceback__)[-1]
+            observed.update(died_with=str(exc), died_at="%s:%d" % (os.path.basename(tb.filename), tb.lineno))
+        V.BertForMultiModalPreTraining.from_pretrained = classmethod(real_from_pretrained)
+        import apex.optimizers as AO
+        observed["apex_optimizers_file"] = os.path.relpath(AO.__file__, ROOT)
+        return observed
     ns = runpy.run_path(sys.argv[0], run_name="__main__")
     V.BertForMultiModalPreTraining.from_pretrained = classmethod(real_from_pretrained)
     ckpts = sorted(f for _d, _s, fs in os.walk(out) for f in fs)
@@ -295,6 +318,6 @@ def run_tasks(work):
 if __name__ == "__main__":
     which, work = sys.argv[1], sys.argv[2]
     _setup_imports()
-    res = run_concap(work) if which == "concap" else run_tasks(work)
+    res = run_concap(work) if which == "concap" else run_concap(work, fp16=True) if which == "concap_fp16" else run_tasks(work)
     res["ok"] = True
     print("DRYRUN " + json.dumps(res))

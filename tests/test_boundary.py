@@ -147,18 +147,29 @@ def test_constructor_and_forward_signatures_equal_the_reference():
         assert str(inspect.signature(getattr(ours.BertConfig, fn))) == str(inspect.signature(getattr(ref.BertConfig, fn)))
 
 
-def test_half_switches_to_the_bf16_training_mode_and_keeps_fp32_master_weights():
+def test_half_switches_this_model_to_the_bf16_mode_and_keeps_fp32_master_weights():
     """The reference's scripts call `model.half()` for reduced-precision training (train_concap.py:504-505) next to an
-    optimizer that keeps fp32 master weights; here that is the bf16 stream: the process switches mode, the parameters stay
+    optimizer that keeps fp32 master weights; here that is the bf16 stream, PER MODEL (round 6): the model's forward runs in
+    the bf16 mode and restores the process-wide mode, a second model is unaffected, `float()` undoes it; the parameters stay
     fp32 (no kernel of the package takes fp16 parameters), the call returns the model like nn.Module.half()."""
     from vilbert import _native
-    m = _build("pretraining", synth.tiny_config())
+    m, other = _build("pretraining", synth.tiny_config()), _build("pretraining", synth.tiny_config())
     prev = _native.set_gemm_mode("f32")
     try:
-        assert not _native.bf16_stream()
+        seen = []
+        for net in (m, other):
+            net.forward = lambda *a, **k: seen.append(_native.bf16_stream())      # (no device here: only the mode is observed)
         assert m.half() is m
-        assert _native.bf16_stream() and _native.set_gemm_mode("bf16") == "bf16"
+        assert not _native.bf16_stream(), "half() must not flip the process-wide mode"
+        m()
+        other()
+        assert seen == [True, False] and not _native.bf16_stream()
         assert all(p.dtype == torch.float32 for p in m.parameters())
+        _native.set_gemm_mode("mxfp8")           # another mode active in the process: restored after the half() model's forward
+        m()
+        assert _native.set_gemm_mode("f32") == "mxfp8"
+        assert m.float() is m
+        m()
+        assert seen[-1] is False
     finally:
         _native.set_gemm_mode(prev)
-    assert not _native.bf16_stream() or prev == "bf16"

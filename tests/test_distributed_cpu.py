@@ -135,6 +135,20 @@ def _algo_worker(rank, world, port, q):
         ddp.arena.release()
     with pytest.raises(ValueError):
         DDP(Net(), algorithm="tree")
+    # defaults (round 6): fp32 training = ring all-reduce of fp32 buckets; a model in the bf16 mode (`model.half()` before the
+    # wrapper, the reference's order train_concap.py:504-513, or the process-wide mode) = direct exchange of bf16 buckets;
+    # explicit arguments win
+    plain = DDP(Net())
+    assert plain.algorithm == "ring" and plain.bucket_dtype is None
+    plain.arena.release()
+    half = Net()
+    half._vb_bf16 = True
+    d = DDP(half)
+    assert d.algorithm == "direct" and d.bucket_dtype == torch.bfloat16
+    d.arena.release()
+    d = DDP(half, algorithm="ring", bucket_dtype=torch.float32)
+    assert d.algorithm == "ring" and d.bucket_dtype is None
+    d.arena.release()
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

@@ -148,3 +148,31 @@ def test_native_adamw_handles_misaligned_views():
         opt.step()
         ao.adamw_step(ref_p, ref_g, ref_m, ref_v, step, 1e-2, (0.9, 0.999), 1e-6, 0.01, True)
     assert (p.detach().cpu() - ref_p).abs().max().item() <= 2e-6 * ref_p.abs().max().item()
+
+
+def test_any_optimizer_step_invalidates_the_derived_weight_caches():
+    """Advisor finding of round 5: the bf16 shadows / fp8 / MX weight caches are refreshed when torch's version counter of a
+    parameter moves or when `_native.weights_changed()` bumps the epoch. An optimizer that writes through `.data` - the
+    reference's RAdam, /root/reference/vilbert/optimization.py:98,174 - does neither by itself; the package registers a global
+    post-step hook, so every torch.optim.Optimizer subclass announces its step."""
+    import torch
+    from vilbert import _native
+
+    class DataWriter(torch.optim.Optimizer):          # the reference RAdam's update style
+        def __init__(self, params):
+            super(DataWriter, self).__init__(params, dict(lr=0.1))
+
+        def step(self, closure=None):
+            for g in self.param_groups:
+                for p in g["params"]:
+                    p.data.copy_(p.data - g["lr"] * p.grad.data)
+
+    w = torch.nn.Parameter(torch.ones(4))
+    w.grad = torch.ones(4)
+    v0, e0 = w._version, _native.WEIGHTS_EPOCH[0]
+    DataWriter([w]).step()
+    assert w._version == v0, "(.data writes are invisible to the version counter - the reason for the hook)"
+    assert _native.WEIGHTS_EPOCH[0] > e0
+    e1 = _native.WEIGHTS_EPOCH[0]
+    torch.optim.SGD([w], lr=0.1).step()
+    assert _native.WEIGHTS_EPOCH[0] > e1

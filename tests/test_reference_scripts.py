@@ -59,6 +59,19 @@ def test_train_concap_main_runs_unmodified(tmp_path):
 
 
 @needs_reference
+def test_train_concap_fp16_branch_reaches_the_references_own_name_error(tmp_path):
+    """`train_concap.py --fp16` (round-5 review, missing 5): `from apex.optimizers import FP16_Optimizer, FusedAdam`
+    (:443-450) resolves to this package's shims on the native AdamW, `FP16_Optimizer(FusedAdam(...), dynamic_loss_scale=True)`
+    is accepted by `WarmupLinearSchedule`, `model.half()` (:504-505) switches the model to the bf16 mode, one forward and
+    `optimizer.backward(loss)` (:570-571) run - and the script then dies exactly where it dies upstream: `warmup_linear` at
+    :576 is a name train_concap.py never imports."""
+    got = _dry_run("concap_fp16", tmp_path)
+    assert got["ok"] and got["half_called"] and got["forward_calls"] == 1
+    assert got["apex_optimizers_file"] == "vilbert-multi-task_amd/apex/optimizers/__init__.py"
+    assert "warmup_linear" in got["died_with"] and got["died_at"].startswith("train_concap.py:57"), got
+
+
+@needs_reference
 def test_train_tasks_main_runs_unmodified(tmp_path):
     """/root/reference/train_tasks.py `main()` on tasks 1-8 (VQA + Flickr30k retrieval): vilbert_tasks.yml through
     easydict, LoadLosses, from_pretrained of a pre-training checkpoint into VILBertForVLTasks, per-parameter groups,

@@ -486,6 +486,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Zero fill of a row-strided fp32 matrix AS A KERNEL (round 6). hipMemset2DAsync / hipMemsetAsync become MEMSET NODES when the
+// step is captured into a HIP graph, and a memset node in front of the kernels that accumulate into the buffer was found not to
+// take effect at replay on this runtime (tools/memset_node_repro.py; the fp8 chain-graph issue of round 5: the split-K input
+// gradient of the MLM decoder then added its partial sums to whatever the block held from the previous replay - e4m3 codes read
+// as fp32 are ~1e38 - and AdamW's second moments overflowed). A kernel node is ordered like every other kernel of the chain.
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ c, long ldc, int rows, int cols) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = (cols + 3) / 4;
+    if (i >= (long)rows * c4) return;
+    const int r = (int)(i / c4), q = (int)(i % c4) * 4;
+    float* __restrict__ d = c + (long)r * ldc + q;
+    if (q + 4 <= cols && ((reinterpret_cast<uintptr_t>(d) & 15u) == 0)) {
+        *reinterpret_cast<f32x4*>(d) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+        for (int e = 0; e < 4 && q + e < cols; ++e) d[e] = 0.f;
+    }
+}
+int zero_rows(hipStream_t st, float* c, long ldc, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const long work = (long)rows * ((cols + 3) / 4);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, c, ldc, rows, cols);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
 // Points the launch at the workspace (-> the kernels store partials instead of adding atomically). false = no slice for
 // this (device, stream) or the slice is too small for `splits` partial copies of C: the caller launches with atomics.
 bool det_prepare(hipStream_t st, GemmP& p, int splits) {
@@ -882,6 +907,12 @@ extern "C" int vb_set_deterministic(int on, void* workspace, int64_t workspace_b
     return prev;
 }
 
+namespace vbgemm {
+bool det_on() { return deterministic(); }
+float* det_slice(hipStream_t st, size_t* slice_bytes) { return det_slice_of(st, slice_bytes); }
+void det_fallback() { det_count_fallback(); }
+}  // namespace vbgemm
+
 extern "C" int64_t vb_deterministic_fallbacks(void) {
     std::lock_guard<std::mutex> lock(g_det_mutex);
     return (int64_t)g_det_fallbacks;
@@ -983,9 +1014,7 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
         auto launch_main = [&](GemmP q, bool vq) -> int {
             if (!split_k) return launch_gemm<true, false>(st, q, vq, 1);
             if (q.epi == EPI_STORE) {
-                const hipError_t e =
-                    hipMemset2DAsync(q.C[0], q.ldc * sizeof(float), 0, (size_t)q.N * sizeof(float), q.M, st);
-                if (e != hipSuccess) return (int)e;
+                if (int e = zero_rows(st, q.C[0], q.ldc, q.M, q.N)) return e;       // (a kernel, not a memset node: see zero_rows)
             }
             q.epi = EPI_ACCUM;
             q.accumulate = 1;
@@ -1018,13 +1047,9 @@ extern "C" int vb_linear_bwd_weight(void* stream, const vb_linear_bwd_weight_arg
     for (int s = 0; s < a->nseg; ++s) {
         if (a->dW[s] == nullptr) return VB_E_SEGMENT;
         if (!a->accumulate) {
-            hipError_t e = hipMemset2DAsync(a->dW[s], a->ldw * sizeof(float), 0, (size_t)a->K * sizeof(float),
-                                            a->seg_n, st);
-            if (e != hipSuccess) return (int)e;
-            if (a->dbias[s] != nullptr) {
-                e = hipMemsetAsync(a->dbias[s], 0, (size_t)a->seg_n * sizeof(float), st);
-                if (e != hipSuccess) return (int)e;
-            }
+            if (int e = zero_rows(st, a->dW[s], a->ldw, a->seg_n, a->K)) return e;
+            if (a->dbias[s] != nullptr)
+                if (int e = zero_rows(st, a->dbias[s], a->seg_n, 1, a->seg_n)) return e;
         }
     }
     {

@@ -442,6 +442,11 @@ struct HwP {
     int nkt, kt_per_split, splits;  // contraction tiles in total / per unit, units per tile
     int units;
     int flags;                      // laboratory (VB_BF16_FLAGS), as HbP
+    // deterministic form (vb_set_deterministic, the default): a unit STORES its partial tile to ws + (split tiles + tile) 32768
+    // floats in accumulator order - [wave][MFMA tile][register quad][lane] float4: every store instruction writes 1 KiB of
+    // consecutive addresses - and its bias-gradient partial to ws_b + split N; wgrad_bf16_reduce_kernel adds the splits in
+    // order into dW / db. nullptr = fp32 atomics straight into dW / db (run-to-run differences in the last bits).
+    float* ws; float* ws_b;
 };
 
 // unit of block `b` in its i-th round: the 32 blocks of an XCD (b % 8) take CONSECUTIVE units - the same contraction split and
@@ -692,6 +697,28 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
         // acc[i][j][rr]: n = n0 + wm 64 + 32 i + 4 hi + (rr & 3) + 8 (rr >> 2), k = k0 + wn 64 + 32 j + l31
         if (p.flags & 8) continue;
         const int seg = n0 / p.cseg;
+        if (p.ws != nullptr) {
+            const int u = hw_unit_of(b, ui, grid, p.units);      // = split * tiles + tile
+            f32x4* __restrict__ w = reinterpret_cast<f32x4*>(p.ws) + ((long)u * 8 + wave) * (4 * 4 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        w[((2 * i + j) * 4 + qq) * 64] =
+                            f32x4{acc[i][j][4 * qq], acc[i][j][4 * qq + 1], acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]};
+            if (do_bias) {
+                const int split = u / p.tiles;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float t = bsum[i] + __shfl_xor(bsum[i], 32);
+                    if (hi == 0) p.ws_b[(long)split * p.N + n0 + wm * 64 + 32 * i + l31] = t;
+                    bsum[i] = 0.f;
+                }
+            }
+            continue;
+        }
         float* __restrict__ cb = p.C[seg] + (long)(n0 - seg * p.cseg + wm * 64 + 4 * hi) * p.ldc + k0 + wn * 64 + l31;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -708,6 +735,36 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
                 bsum[i] = 0.f;
             }
         }
+    }
+}
+
+// Second pass of the deterministic weight gradient: dW += sum over the splits, IN SPLIT ORDER, of the partial tiles the units
+// stored in accumulator order; db likewise. One thread per float4 of a tile (the four values are four ROWS of one column: lane
+// l31 -> consecutive k, so a half-wave reads and writes 128 consecutive bytes of a dW row), the last blocks take the bias.
+__global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const HwP p) {
+    const long n4 = (long)p.tiles * 8192;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n4) {
+        const int t = (int)(idx >> 13), in = (int)(idx & 8191);
+        const int wave = in >> 10, ij = (in >> 8) & 3, qq = (in >> 6) & 3, lane = in & 63;
+        const int l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1, i = ij >> 1, j = ij & 1;
+        const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(p.ws) + idx;
+        f32x4 a = w[0];
+        for (int s = 1; s < p.splits; ++s) a += w[(long)s * n4];
+        const int n0 = (t / p.tiles_k) * HB_BM, k0 = (t % p.tiles_k) * HB_BN;
+        const int seg = n0 / p.cseg;
+        float* __restrict__ c = p.C[seg] + (long)(n0 - seg * p.cseg + wm * 64 + 32 * i + 4 * hi + 8 * qq) * p.ldc + k0 + wn * 64 +
+                                32 * j + l31;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[(long)e * p.ldc] += a[e];
+    } else {
+        const long n = idx - n4;
+        if (n >= p.N) return;
+        const int seg = (int)(n / p.cseg);
+        if (p.bias[seg] == nullptr) return;
+        float a = p.ws_b[n];
+        for (int s = 1; s < p.splits; ++s) a += p.ws_b[(long)s * p.N + n];
+        p.bias[seg][n - (long)seg * p.cseg] += a;
     }
 }
 
@@ -915,18 +972,37 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     // loop and lengthen the atomics: the first version's "fill two rounds" rule spent 30 - 50 % of a launch in atomics.
     static const float t_k = [] { const char* e = getenv("VB_BF16_WG_TK"); return e ? (float)atof(e) : 1.0f; }();
     static const float t_e = [] { const char* e = getenv("VB_BF16_WG_TE"); return e ? (float)atof(e) : 0.12f; }();
+    // deterministic form: a unit's 128 KiB leave as plain 16-byte stores (t_d per unit), and the reduce pass reads every
+    // partial once and updates dW: (splits + 2) x 4 N K bytes at ~3.5 TB/s + its launch
+    static const float t_d = [] { const char* e = getenv("VB_BF16_WG_TD"); return e ? (float)atof(e) : 0.04f; }();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t slice_bytes = 0;
+    float* slice = det_on() ? det_slice(st, &slice_bytes) : nullptr;
+    const size_t per_split = ((size_t)p.tiles * 32768 + (size_t)p.N) * sizeof(float);
     int best = 1;
     float best_t = 1e30f;
     for (int sp = 1; sp <= p.nkt && sp <= 64; ++sp) {
         const int per = (p.nkt + sp - 1) / sp, real = (p.nkt + per - 1) / per;
         if (real != sp) continue;
         const long units = (long)p.tiles * sp;
-        const float t = (float)((units + 255) / 256) * (per * t_k + 2.0f) + units * t_e;
+        float t = (float)((units + 255) / 256) * (per * t_k + 2.0f);
+        if (slice != nullptr) {
+            if ((size_t)sp * per_split > slice_bytes) continue;
+            t += units * t_d + 3.0f + (float)(sp + 2) * (4.0f * p.N * p.K) / 3.5e6f;
+        } else {
+            t += units * t_e;
+        }
         if (t < best_t) { best_t = t; best = sp; }
     }
+    if (best_t >= 1e30f) slice = nullptr;          // (not even one split fits the slice)
+    if (det_on() && slice == nullptr) det_fallback();
     p.kt_per_split = (p.nkt + best - 1) / best;
     p.splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
     p.units = p.tiles * p.splits;
+    if (slice != nullptr) {
+        p.ws = slice;
+        p.ws_b = slice + (size_t)p.splits * p.tiles * 32768;
+    }
     static const int lab_flags = [] { const char* e = getenv("VB_BF16_FLAGS"); return e ? atoi(e) : 0; }();
     p.flags = lab_flags;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel),
@@ -934,8 +1010,13 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
     if (attr != hipSuccess) return (int)attr;
     const int cus = hb_grid_limit();
     const int grid = p.units < cus ? (p.units + 7) / 8 * 8 : cus;
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(grid), dim3(HB_THREADS), HB_LDS, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(grid), dim3(HB_THREADS), HB_LDS, st, p);
     VB_LAUNCH_CHECK();
+    if (p.ws != nullptr && !(p.flags & 8)) {
+        const long work = (long)p.tiles * 8192 + p.N;
+        hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, p);
+        VB_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -241,6 +241,12 @@ int launch_gemm_v4_nn(hipStream_t st, const GemmP& p, int tn);
 // persistent weight-gradient kernel (gemm_v4w.h); the launch parameters are filled by plan_v4w (gemm.hip)
 int launch_gemm_v4_tn(hipStream_t st, const GemmP& p, int cfg);
 
+// Deterministic split-K workspace (gemm.hip, vb_set_deterministic) for the kernels of other translation units (gemm_bf16.hip):
+// det_on() = the setting; det_slice(stream, &bytes) = the slice of (current device, stream) or nullptr (no workspace / all
+// slices taken); det_fallback() counts a launch that ran with atomics although the setting is on.
+bool det_on();
+float* det_slice(hipStream_t st, size_t* slice_bytes);
+void det_fallback();
 // bf16-planes kernels (gemm_planes.hip, one object per plane count): launch for operand layouts (a_kc, b_kc)
 int launch_gemm_planes3(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);
 int launch_gemm_planes2(hipStream_t st, const GemmP& p, bool vec, int splits, bool a_kc, bool b_kc);

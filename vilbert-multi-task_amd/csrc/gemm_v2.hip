@@ -5,9 +5,6 @@
 // Each object instantiates the tile menu {64x64, 96x96, 96x128, 128x96, 128x128} (block tile = 32 TM x 32 TN) and the
 // mixed-height launches {128 | 96} x {128, 96}, {96 | 64} x {128, 96}.
 #include "gemm_v4w.h"
-#ifdef VB_GEMM_LAB
-#include "gemm_v3.h"      // the rejected 5-wave design: laboratory build only
-#endif
 
 #ifndef VB_V2_LAYOUT
 #error "compile with -DVB_V2_LAYOUT=0|1|2"
@@ -39,35 +36,10 @@ __global__ __launch_bounds__(256, (V2Cfg<TM1, TN, A_KC, B_KC>::OCC)) void gemm_v
     }
 }
 
-#ifdef VB_GEMM_LAB
-// (laboratory only: measured slower - three 5-wave blocks do not co-reside on a CU - kept as the record of the experiment)
-// wave-specialised variant (gemm_v3.h): 4 MFMA waves + 1 LDS-DMA loader wave per block, same tile map
-template <int TM1, int TM2, int TN>
-__global__ __launch_bounds__(320, (V3Cfg<TM1, TN, A_KC, B_KC>::MIN_WAVES_PER_SIMD)) void gemm_v3_kernel(const GemmP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x;
-    if (TM1 == TM2 || b < p.n_big) {
-        const int t = xcd_swizzle(b, TM1 == TM2 ? (int)gridDim.x : p.n_big);
-        gemm_tile_v3<TM1, TN, A_KC, B_KC>(p, smem, (t / p.tiles_n) * (32 * TM1), (t % p.tiles_n) * (32 * TN));
-    } else {
-        const int t = xcd_swizzle(b - p.n_big, (int)gridDim.x - p.n_big);
-        gemm_tile_v3<TM2, TN, A_KC, B_KC>(p, smem, p.m_split + (t / p.tiles_n) * (32 * TM2), (t % p.tiles_n) * (32 * TN));
-    }
-}
-
-#endif
-
 template <int TM1, int TM2, int TN>
 int launch(hipStream_t st, const GemmP& p, int tiles, int splits) {
     using Cfg = V2Cfg<TM1, TN, A_KC, B_KC>;   // TM1 >= TM2: the taller tile sets the LDS size and the register budget
     dim3 grid(tiles, splits), block(256);
-#ifdef VB_GEMM_LAB
-    if (p.flags & 2) {
-        hipLaunchKernelGGL((gemm_v3_kernel<TM1, TM2, TN>), grid, dim3(320), (V3Cfg<TM1, TN, A_KC, B_KC>::LDS_BYTES), st, p);
-        VB_LAUNCH_CHECK();
-        return 0;
-    }
-#endif
     // lab knob: extra dynamic LDS per block = fewer co-resident blocks per CU (occupancy experiments)
     static const int lds_pad = [] { const char* e = getenv("VB_GEMM_LDS_PAD"); return e ? atoi(e) : 0; }();
     const int lds_bytes = Cfg::LDS_BYTES + lds_pad;

@@ -349,6 +349,11 @@ def ensure_deterministic(device):
             _register_workspace(device)
 
 
+def deterministic_enabled():
+    """The setting itself (VB_DETERMINISTIC / set_deterministic): ordered split-K reduces wanted."""
+    return bool(_DET["wanted"])
+
+
 def deterministic_workspace(device=None):
     """The workspace tensor registered for `device` (None if none): GraphedTrainStep holds it while its graph lives."""
     import torch
@@ -422,6 +427,18 @@ WEIGHTS_EPOCH = [0]
 
 def weights_changed():
     WEIGHTS_EPOCH[0] += 1
+
+
+# ANY optimizer announces its step (round 6, advisor finding): an optimizer that writes through `.data` - the reference's RAdam
+# does, /root/reference/vilbert/optimization.py:98,174 `p.data.copy_(...)`, selected by train_tasks.py --optim RAdam - bumps
+# neither torch's version counters nor (not being the native AdamW) this epoch, and the bf16 shadows / fp8 / MX weight caches
+# would keep serving the initial weights while the fp32 masters move. torch calls global post-step hooks for every
+# torch.optim.Optimizer subclass, whatever its step() does.
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step
+    _register_post_step(lambda _opt, _args, _kwargs: weights_changed())
+except ImportError:      # pragma: no cover  (a torch without global optimizer hooks: the native AdamW still announces itself)
+    pass
 
 
 def check(code, what):

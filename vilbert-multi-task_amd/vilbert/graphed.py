@@ -62,14 +62,19 @@ class GraphedTrainStep(object):
         opt-in fp8 training mode ("fp8", "fp8+bf16") replays wrong losses from the third replay on once the process has freed
         device memory before the capture (tools/dbg_graph_nan.py S5 / S6; fork, fp32 and bf16 chains are not affected) - those
         modes therefore keep the forked form, which every round's suite has covered."""
+        base = model.module if hasattr(model, "module") else model
+        bf16 = N.bf16_stream() or bool(getattr(base, "_vb_bf16", False))      # (process-wide mode, or model.half())
         if branches is None:
-            branches = "chain" if N.bf16_stream() else "fork"
+            branches = "chain" if bf16 else "fork"
         if branches not in ("chain", "fork"):
             raise ValueError("branches: chain | fork")
+        if bf16 and warmup < 2:
+            # the device table of the one-launch shadow refresh is built by the first forward AFTER an optimizer step
+            # (ops16.refresh_stale): that must be an eager warm-up step, not the capture
+            raise ValueError("GraphedTrainStep in the bf16 mode needs warmup >= 2")
         self.branches = branches
         self.model, self.opt = model, optimizer
         self.loss_fn = loss_fn or _default_loss
-        base = model.module if hasattr(model, "module") else model
         prev_capacity = getattr(base, "label_capacity", None)
         if hasattr(base, "label_capacity"):
             base.label_capacity = label_capacity

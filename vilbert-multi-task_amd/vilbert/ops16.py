@@ -112,9 +112,24 @@ def _refresh_all(device):
     if t["n"]:
         N.check(N.lib().vb_weight_shadow_multi(N.stream_ptr(), t["n"], t["tab"].data_ptr(), t["tiles"]), "vb_weight_shadow_multi")
     ep = _WEIGHTS_EPOCH[0]
+    t["epoch"] = ep
     for _k, e in live:
         e.epoch = ep
         e.vers = tuple(r()._version for r in e.wrefs)
+
+
+def refresh_stale(device):
+    """Start of a model forward (BertModel.forward, on the stream the text / image branches fork from): when the weights
+    epoch moved since the shadows of `device` were refreshed - an optimizer stepped - refresh all of them now, with the one
+    launch over the device table (built here, eagerly, so that it never is built inside a stream capture or a branch)."""
+    ep = _WEIGHTS_EPOCH[0]
+    t = _TABLES.get(device.index)
+    if t is not None and t.get("epoch") == ep:
+        return
+    if not any(e.w16.device.index == device.index for e in _SHADOWS.values()):
+        return
+    with torch.no_grad():
+        _refresh_all(device)
 
 
 def shadows(weights, biases=None):
@@ -234,7 +249,9 @@ def linear_bwd_input(dy, weights, biases, in_features, residual=None, mul=None):
 def linear_bwd_weight(dy, x, nseg, seg_n, want_bias, dw_out=None, db_out=None):
     """Per segment: dW_s += dY[:, s]^T @ X (fp32, atomics into the targets) and db_s += colsum(dY[:, s]) - one launch, the
     bias gradient comes out of the fragments the weight-gradient kernel holds anyway. dy / x bf16.
-    Same contract as ops.linear_bwd_weight: targets not given are slices of one zero-filled buffer allocated here."""
+    Same contract as ops.linear_bwd_weight: targets not given are slices of one zero-filled buffer allocated here.
+    Deterministic setting on (default): the contraction splits go through the per-stream workspace and an ordered reduce."""
+    N.ensure_deterministic(dy.device)
     n = nseg * seg_n
     dy2, _ = _rows2(dy, n)
     K = x.shape[-1]

@@ -825,12 +825,27 @@ class BertPreTrainedModel(PreTrainedModel):
         """What the reference's scripts call for reduced-precision training (`model.half()` next to apex's FP16_Optimizer,
         which keeps fp32 master weights: train_concap.py:443-461,504-505; train_tasks.py:168-171). Here that mode is the bf16
         stream of DESIGN.md section 4.5: activations, saved tensors and activation gradients become bfloat16, the parameters
-        STAY fp32 (they are the master weights; the kernels keep their own bf16 copies) - so this switches the process into
-        `_native.set_gemm_mode("bf16")` and returns the model unchanged, instead of casting parameters to fp16, which no
-        kernel of this package takes. `_native.set_gemm_mode("f32")` switches back."""
-        _native.set_gemm_mode("bf16")
-        logger.info("half(): bf16 training mode on (bfloat16 activations / gradients, fp32 master weights); parameters unchanged")
+        STAY fp32 (they are the master weights; the kernels keep their own bf16 copies). The switch belongs to THIS model
+        (round 6): its forward runs under `_native.set_gemm_mode("bf16")` and restores the process-wide mode afterwards, so a
+        second model in the process (an evaluation copy, an fp8 / MX inference model) keeps its own arithmetic; `float()`
+        undoes it. Backward needs no mode: the autograd nodes the bf16 forward recorded call the bf16 kernels directly."""
+        self._vb_bf16 = True
+        logger.info("half(): bf16 mode on for this model (bfloat16 activations / gradients, fp32 master weights); "
+                    "parameters unchanged")
         return self
+
+    def float(self):
+        self._vb_bf16 = False
+        return super(BertPreTrainedModel, self).float()
+
+    def __call__(self, *args, **kwargs):
+        if getattr(self, "_vb_bf16", False) and not _native.bf16_stream():
+            prev = _native.set_gemm_mode("bf16")
+            try:
+                return super(BertPreTrainedModel, self).__call__(*args, **kwargs)
+            finally:
+                _native.set_gemm_mode(prev)
+        return super(BertPreTrainedModel, self).__call__(*args, **kwargs)
 
     def init_weights(self, module):
         if isinstance(module, (nn.Linear, nn.Embedding)):
@@ -912,6 +927,12 @@ class BertModel(BertPreTrainedModel):
         extended_co_attention_mask = (co_attention_mask.unsqueeze(1) * 5.0).to(
             dtype=next(self.parameters()).dtype)
 
+        if _native.bf16_stream() and input_imgs.is_cuda:
+            # the one-launch refresh of every bf16 weight shadow runs HERE, on the stream the text / image branches fork from
+            # (advisor finding of round 5: left to the first linear that asks, it could run inside one branch while the
+            # other already reads shadows)
+            from . import ops16
+            ops16.refresh_stale(input_imgs.device)
         embedding_output = self.embeddings(input_txt, token_type_ids, task_ids)
         v_embedding_output = self.v_embeddings(input_imgs, image_loc)
         if _native.bf16_stream() and embedding_output.is_cuda and not self.config.dynamic_attention:
