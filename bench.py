@@ -374,8 +374,10 @@ def main():
     def gemm_family_tf(fn):
         """TFLOP/s of all GEMM launches of one extra single-stream call of fn (HIP events around every launch)."""
         from vilbert import autograd_ops as _ao2
+        from vilbert import layers as _ly2
         from vilbert import vilbert as _vb2
         two_, ws_ = _vb2.set_two_streams(False), _ao2.set_wgrad_stream(False)
+        nat_ = _ly2.set_native(False)      # per-launch events live in the per-op launchers (same kernels, same order)
         try:
             fn()
             torch.cuda.synchronize()
@@ -386,6 +388,7 @@ def main():
         finally:
             _vb2.set_two_streams(two_)
             _ao2.set_wgrad_stream(ws_)
+            _ly2.set_native(nat_)
         return (fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0), n
 
     def bf16_roofline(tf, n):
@@ -397,8 +400,9 @@ def main():
                 "what": "all GEMM launches of one extra step (fwd + dgrad + wgrad), algorithmic 2MNK FLOPs / sum of HIP-event "
                         "durations (single stream); bf16 dense MFMA peak 2500 TF"}
 
-    def comm_model(step64_ms):
-        """What the gradient exchange will cost at N = 8, from what CAN be measured on one GPU: the real bucket layout
+    def comm_model(step64_ms, mibs=(64, 256)):
+        """(In the bf16 GEMM mode - switched on by the caller - the wrapper defaults to bf16 exchange buckets and the direct
+        algorithm: half the bytes on the links.) What the gradient exchange will cost at N = 8, from what CAN be measured on one GPU: the real bucket layout
         (vilbert/distributed.py, buckets of 64 MiB = the default since round 3 and of 256 MiB over the gradient arena), the moment each bucket's all-reduce is
         launched inside backward (HIP events, world-size-1 RCCL group) and therefore the window of backward work left to
         hide it, next to SURVEY.md section 8(e)'s xGMI cost model (7 links x ~153 GB/s per GPU: ring all-reduce
@@ -415,8 +419,10 @@ def main():
         link = 153e9
         out = {"what": "model (not a measurement of N > 1): bucket sizes and launch times measured on one GPU, xGMI cost from "
                        "SURVEY.md 8(e)", "n_gpus_modelled": 8}
-        for mib in (64, 256):        # 64 MiB = the wrapper's default since round 3, 256 MiB = rounds 1-2
+        for mib in mibs:        # 64 MiB = the wrapper's default since round 3, 256 MiB = rounds 1-2
             net = DistributedDataParallel(build_model(cfg, "pretraining", device).train(), message_size=mib * (1 << 20) // 4)
+            out["bucket_dtype"] = str(net.bucket_dtype) if net.bucket_dtype is not None else "torch.float32"
+            out["algorithm_default"] = net.algorithm
             optim = AdamW(net.parameters(), lr=1e-4, betas=(0.9, 0.98))
             res = {"n_buckets": len(net._buckets)}
             for pb in (64, 256):
@@ -441,6 +447,8 @@ def main():
                 bwd_ms = e0.elapsed_time(e1)
                 rows, t_ring, t_direct = [], 0.0, 0.0
                 for idx, nbytes, ev in net.trace:
+                    if net.bucket_dtype is torch.bfloat16:
+                        nbytes //= 2                                     # (the trace reports the fp32 arena range)
                     ready = e0.elapsed_time(ev)
                     ring = 2.0 * 7 / 8 * nbytes / link * 1e3
                     direct = 2.0 * (nbytes / 8) / link * 1e3
@@ -654,6 +662,8 @@ def main():
     from vilbert import vilbert as _vb
     two = _vb.set_two_streams(False)
     ws_prev = _ao.set_wgrad_stream(False)
+    from vilbert import layers as _ly
+    nat_prev = _ly.set_native(False)       # per-launch events live in the per-op launchers (same kernels, same order)
     pstep = step
     if args.graph and args.mode == "train":
         pstep = train_workload(B)[0]      # per-launch events need eager launches (same model, same optimizer)
@@ -666,6 +676,7 @@ def main():
     gemm_ms, gemm_flops, gemm_launches = ops.profile_linear(False)
     _vb.set_two_streams(two)
     _ao.set_wgrad_stream(ws_prev)
+    _ly.set_native(nat_prev)
     if args.gemm_breakdown and rank == 0:
         for tag, n, ms, tf in ops.profile_breakdown():
             print("gemm %-6s M=%6d N=%6d K=%6d nseg=%d  x%3d  %8.3f ms  %6.1f TF" % (tag + (n, ms, tf)), file=sys.stderr)
@@ -820,6 +831,12 @@ def main():
             for gs_ in train_state.pop("graphs", []):
                 gs_.close()
             del g64_16
+            # the exchange of the bf16 step: bf16 buckets + the direct algorithm (the wrapper's defaults in this mode)
+            _native.set_gemm_mode("bf16")
+            try:
+                b64_["comm_model"] = comm_model(b64_["ms_per_step"], mibs=(64,))
+            finally:
+                _native.set_gemm_mode("f32")
         # the train model, its optimizer state and arena are not needed below
         for k in list(train_state):
             train_state.pop(k)
@@ -837,6 +854,39 @@ def main():
         if not args.no_cpu_baseline:
             # north_star: "next to the reference CPU forward timed on the node's own host cores (core count stated)"
             extra["fwd_b512"]["cpu_baseline"] = cpu_baseline(cfg, "fwd", budget_s=15.0)
+        ref_out = [o.float() for o in fstep()[:3]]      # fp32 HIP forward of the same model / inputs (pinned to the oracle at 1e-6)
+
+        def rank_stats(outs):
+            """What a user of a reduced-precision inference mode sees: agreement of the ranking heads with the fp32 forward of
+            the same (random-init) model on the same 512 samples (tests/test_mx_bench_shapes_gpu.py holds the oracle-side twin)."""
+            vq, vq_ref = outs[0].float(), ref_out[0]
+            top1 = float((vq.argmax(1) == vq_ref.argmax(1)).float().mean())
+            in5 = float((vq.topk(5, dim=1).indices == vq_ref.argmax(1, keepdim=True)).any(1).float().mean())
+            a, b = outs[2].float().view(-1), ref_out[2].view(-1)
+            ra, rb = a.argsort().argsort().double(), b.argsort().argsort().double()
+            rho = float(((ra - ra.mean()) * (rb - rb.mean())).sum() / ((ra - ra.mean()).norm() * (rb - rb.mean()).norm()))
+            l2 = float((vq.double() - vq_ref.double()).norm() / vq_ref.double().norm())
+            return {"vqa_top1_agreement": round(top1, 3), "fp32_top1_in_top5": round(in5, 3),
+                    "retrieval_score_spearman": round(rho, 3), "vqa_logits_rel_l2": round(l2, 4),
+                    "vs": "the fp32 forward of the same random-init model, 512 samples"}
+
+        # round 6: the bf16 stream (bf16 tensors in HBM, v_mfma_f32_32x32x16_bf16, fp32 LayerNorm / softmax statistics) as an
+        # INFERENCE mode - BASELINE.md section 4 row 2 names "fp32-MFMA (parity) / bf16" for this point
+        _native.set_gemm_mode("bf16")
+        try:
+            fb_dt = timed(fstep, 2, n_f)
+            fb_tf = 512 * n_f / fb_dt * f_total / 1e12
+            tf16f, n16f = gemm_family_tf(fstep)
+            extra["fwd_bf16_b512"] = {"value": round(512 * n_f / fb_dt, 2), "unit": "samples/s",
+                                      "ms_per_step": round(1e3 * fb_dt / n_f, 3), "steps": n_f, "dtype": BF16_DTYPE,
+                                      "speedup_vs_fp32": round(f_dt / fb_dt, 2), "model_tflops": round(fb_tf, 1),
+                                      "frac_of_bf16_mfma_peak": round(fb_tf / 2500.0, 4),
+                                      "rank_statistics": rank_stats(fstep()),
+                                      "roofline": bf16_roofline(tf16f, n16f),
+                                      "note": "the same forward on the bf16 stream of the training mode (eval, no_grad): outside the "
+                                              "1e-4 parity bar by design; drift bounds tests/test_bf16_stream_gpu.py"}
+        finally:
+            _native.set_gemm_mode("f32")
         # BASELINE configs[4]: the same forward with the linears on quantised e4m3 operands (csrc/fp8.hip). Per-row
         # scales, fp32 accumulate / LayerNorm / attention; outside the 1e-4 bar by design (tests/test_fp8_gpu.py).
         _native.set_gemm_mode("fp8")
@@ -875,7 +925,8 @@ def main():
                                                "epilogue (no quantiser pass, no fp32 FFN activation); residual stream between the layers "
                                                "in %s, attention on bf16 q | k | v with fp32 softmax and an MX context, LayerNorm "
                                                "statistics fp32; fp8 dense MFMA peak 5000 TF" % os.environ.get("VB_MX_STREAM", "bf16"),
-                                       "mx_stream": os.environ.get("VB_MX_STREAM", "bf16")}
+                                       "mx_stream": os.environ.get("VB_MX_STREAM", "bf16"),
+                                       "rank_statistics": rank_stats(fstep())}
             # its own roofline object: every MX / fp8 GEMM launch of two more forwards bracketed with HIP events, single stream
             # (as the headline's); bound: the scaled-MFMA peak. Counter-side bytes of the dominant launch: tools/pmc_mx.sh
             two_mx = _vb.set_two_streams(False)
@@ -915,7 +966,7 @@ def main():
             del emx, gmx
         finally:
             _native.set_gemm_mode("f32")
-        del fstep, fmodel
+        del fstep, fmodel, ref_out
         torch.cuda.empty_cache()
         extra.update(large_legs())
         torch.cuda.empty_cache()
@@ -1022,6 +1073,41 @@ def main():
                 line["roofline"]["traffic_note"] = "not measured for this mode"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.mode)
+        # the legs a reader needs first, again, as the LAST key: the driver keeps the final 8 KB of stdout
+        def pick(d, *keys):
+            for k in keys:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        summ = {"headline_samples_per_s": line["value"], "headline_ms_per_step": line["ms_per_step"],
+                "headline_roofline_frac": line["roofline"]["frac"],
+                "b64": pick(line, "b64", "value"), "global512_one_gpu": pick(line, "global512", "value"),
+                "fwd_b512": pick(line, "fwd_b512", "value"), "fwd_b512_frac": pick(line, "fwd_b512", "frac_of_fp32_mfma_peak"),
+                "fwd_bf16_b512": pick(line, "fwd_bf16_b512", "value"),
+                "fwd_bf16_b512_gemm_frac": pick(line, "fwd_bf16_b512", "roofline", "frac"),
+                "fwd_bf16_b512_rank": pick(line, "fwd_bf16_b512", "rank_statistics"),
+                "fwd_mxfp8_b512": pick(line, "fwd_mxfp8_b512", "value"),
+                "fwd_mxfp8_b512_gemm_frac": pick(line, "fwd_mxfp8_b512", "roofline", "frac"),
+                "fwd_mxfp8_b512_rank": pick(line, "fwd_mxfp8_b512", "rank_statistics"),
+                "train_bf16_b256": pick(line, "alt_gemm_modes", "bf16", "value"),
+                "train_bf16_gemm_frac": pick(line, "alt_gemm_modes", "bf16", "roofline", "frac"),
+                "train_bf16_b64": pick(line, "alt_gemm_modes", "bf16", "b64", "value"),
+                "train_bf16_b64_eager": pick(line, "alt_gemm_modes", "bf16", "b64", "eager"),
+                "train_bf16_b64_graphed": pick(line, "alt_gemm_modes", "bf16", "b64", "graphed")}
+        pred = pick(line, "comm_model", "buckets_64_mib", "predicted_global512_n8")
+        g512 = summ["global512_one_gpu"]
+        if pred and g512:
+            summ["n8_model_fp32"] = {"samples_per_s_ring": pred["samples_per_s_ring"], "samples_per_s_direct": pred["samples_per_s_direct"],
+                                     "x_one_gpu_ring": round(pred["samples_per_s_ring"] / g512, 2),
+                                     "x_one_gpu_direct": round(pred["samples_per_s_direct"] / g512, 2),
+                                     "what": "MODEL of 8 x 64 samples (measured one-GPU step at 64 + exposed exchange) / measured "
+                                             "one-GPU rate at global batch 512"}
+        pred16 = pick(line, "alt_gemm_modes", "bf16", "b64", "comm_model", "buckets_64_mib", "predicted_global512_n8")
+        if pred16 and summ["train_bf16_b256"]:
+            summ["n8_model_bf16"] = {"samples_per_s_ring": pred16["samples_per_s_ring"],
+                                     "samples_per_s_direct": pred16["samples_per_s_direct"],
+                                     "x_one_gpu_b256_direct": round(pred16["samples_per_s_direct"] / summ["train_bf16_b256"], 2),
+                                     "what": "MODEL, bf16 buckets: 8 x 64 samples / the measured one-GPU bf16 rate at batch 256"}
+        line["summary"] = summ
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

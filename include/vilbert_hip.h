@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 16
+#define VB_ABI_VERSION 17
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -686,6 +686,98 @@ int64_t vb_layernorm_bwd_bf16_workspace(int64_t rows, int32_t n_cols);
 int vb_layernorm_bwd_bf16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* dy, const uint16_t* x, const float* mean,
                           const float* rstd, const float* gamma, uint16_t* dx, float* dgamma, float* dbeta, float* workspace,
                           uint16_t* dx_dropped, float dropout_p, uint64_t seed);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-layer entry points (round 6; SURVEY.md section 8(b) "vb_text_layer_fwd ... vb_connection_layer_fwd"): ONE call
+ * enqueues the kernel sequence of a BertLayer / BertImageLayer (reference vilbert.py:527-533, 688-694) or of a
+ * BertConnectionLayer (:871-900) - forward, or backward including every weight gradient - into caller-allocated buffers.
+ * Same kernels, same arithmetic and same order as the per-op entry points above (the launcher only calls those); what it
+ * removes is the host work between them: at the reference's per-GPU batch 64 the eager step was bound by ~1,400 Python ->
+ * ctypes launches per step.
+ *
+ * dtype: VB_DT_F32 = fp32 tensors (vb_linear_fwd / vb_attention_fwd / vb_layernorm_fwd ...), VB_DT_BF16 = the bf16
+ * training path (vb_linear_bf16 on the weight shadows, ...); every `void*` activation below has that element type,
+ * leading dimension = its width (contiguous rows). Layer = attention block + one ("self" layers) or two (connection
+ * layer: stream 1 = image regions, stream 2 = text tokens) output + feed-forward blocks:
+ *
+ *   attention block, self (n2 == 0):  qkv1_out = x1 . [Wq|Wk|Wv]^T + b;  ctx1 = attn(q, k, v | mask1, p1, seed1)
+ *   attention block, co-attention:    qkv1_out = x1 . W1^T, qkv2_out = x2 . W2^T;
+ *                                     ctx1 = attn(q2; k1, v1 | mask1, p1) [batch n2 rows: the TEXT stream's context],
+ *                                     ctx2 = attn(q1; k2, v2 | mask2, p2) [batch n1 rows: the IMAGE stream's] (:768-809)
+ *   output + FFN block:  sum1 = dropout(ctx . Wo^T + bo, p_o, seed_o) + x;   a1 = LayerNorm(sum1)
+ *                        h = gelu(a1 . W1^T + b1), dact = gelu'(.) (training);  sum2 = dropout(h . W2^T + b2, p_f, seed_f) + a1
+ *                        y = LayerNorm(sum2)
+ * The caller wires the blocks: s1.ctx = the attention block's ctx1 (self) / ctx2 (co-attention), s2.ctx = ctx1; in backward
+ * attn.d_ctx* = the blocks' d_ctx and attn.dres* = the blocks' d_sum1 (the gradient arriving over the skip connection, added
+ * in the epilogue of the q|k|v input-gradient GEMM: dx = dqkv . W + dres).
+ * Backward: weight / bias gradients are ADDED into dw / dbias (gradient-arena semantics; all of a linear's targets given, or
+ * none: NULL skips that weight gradient), dgamma / dbeta are OVERWRITTEN. wgrad_stream != NULL: the weight-gradient launches
+ * go to that stream behind an event of the launch stream (the caller joins it before the gradients are read).
+ * ------------------------------------------------------------------------------------------ */
+#define VB_DT_F32 0
+#define VB_DT_BF16 1
+
+typedef struct {
+    int32_t nseg, seg_n, K;                    /* nseg stacked nn.Linear weights [seg_n, K] */
+    const float* w[VB_MAX_SEGMENTS];           /* fp32 weights (the GEMM operands of the fp32 path) */
+    const float* bias[VB_MAX_SEGMENTS];
+    const uint16_t* w16;                       /* bf16 path: row-major shadow [nseg seg_n, K] */
+    const uint16_t* wt16;                      /* bf16 path: transposed shadow [K, nseg seg_n] */
+    float* dw[VB_MAX_SEGMENTS];                /* backward targets, ADDED into */
+    float* dbias[VB_MAX_SEGMENTS];
+} vb_layer_linear;
+
+typedef struct {
+    const float* gamma;
+    const float* beta;
+    float* dgamma;                             /* backward, OVERWRITTEN */
+    float* dbeta;
+} vb_layer_norm;
+
+typedef struct {
+    int64_t M;                                 /* rows; 0 = block absent */
+    int32_t Hc, H, I;                          /* context width, hidden size, intermediate size */
+    const void* ctx;                           /* [M, Hc] */
+    const void* x;                             /* [M, H] the layer's input (residual) */
+    vb_layer_linear o, f1, f2;
+    vb_layer_norm ln1, ln2;
+    float eps, p_o, p_f;
+    uint64_t seed_o, seed_f;
+    void* sum1; void* a1; void* h; void* dact; void* sum2; void* y;      /* [M,H] [M,H] [M,I] [M,I] [M,H] [M,H] */
+    float* mean1; float* rstd1; float* mean2; float* rstd2;              /* [M] each (training) */
+    const void* dy;                            /* backward: [M, H] */
+    void* d_sum2; void* d_sum2_drop; void* d_pre; void* d_a1; void* d_sum1; void* d_sum1_drop; void* d_ctx;
+    float* ln_ws;                              /* vb_layernorm_bwd(_bf16)_workspace(M, H) floats */
+} vb_ffn_block;
+
+typedef struct {
+    int32_t batch, heads, head_dim, n1, n2;    /* n2 == 0: self-attention */
+    const void* x1; const void* x2;            /* [batch n1, K1], [batch n2, K2] */
+    const float* mask1; const float* mask2;    /* additive fp32 [batch, n1] / [batch, n2] */
+    vb_layer_linear qkv1, qkv2;
+    float p1, p2;
+    uint64_t seed1, seed2;
+    void* qkv1_out; void* qkv2_out;            /* [batch n1, 3 Hb], [batch n2, 3 Hb], Hb = heads head_dim */
+    float* lse1; float* lse2;                  /* [batch, heads, n_q] (training) */
+    void* ctx1; void* ctx2;
+    const void* d_ctx1; const void* d_ctx2;    /* backward */
+    void* dqkv1; void* dqkv2;
+    float* dvec;                               /* scratch [batch, heads, max(n1, n2)] */
+    const void* dres1; const void* dres2;
+    void* dx1; void* dx2;
+} vb_attn_block;
+
+typedef struct {
+    int32_t dtype;                             /* VB_DT_F32 | VB_DT_BF16 */
+    int32_t training;                          /* forward: store what backward needs (lse, mean / rstd, dact) */
+    void* wgrad_stream;                        /* backward: stream of the weight-gradient launches, or NULL */
+    vb_attn_block attn;
+    vb_ffn_block s1;
+    vb_ffn_block s2;
+} vb_layer_args;
+
+int vb_layer_fwd(void* stream, const vb_layer_args* a);
+int vb_layer_bwd(void* stream, const vb_layer_args* a);
 
 #ifdef __cplusplus
 }

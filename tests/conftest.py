@@ -28,3 +28,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def per_op_path():
+    """Tests that watch the per-op launchers (ops.py / ops16.py call counts, the dropout hand-over between autograd nodes)
+    switch the whole-layer launcher (vilbert/layers.py, round 6) off for their duration."""
+    from vilbert import layers
+    prev = layers.set_native(False)
+    yield
+    layers.set_native(prev)

@@ -38,7 +38,9 @@ EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fw
                # round 5: the bf16 training path (csrc/gemm_bf16.hip, rowops16.hip)
                "vb_attention_fwd_bf16", "vb_attention_bwd_bf16", "vb_linear_bf16", "vb_wgrad_bf16", "vb_colsum_bf16_workspace", "vb_colsum_bf16", "vb_weight_shadow_bf16", "vb_weight_shadow_multi",
                "vb_cast_f32_bf16", "vb_cast_bf16_f32", "vb_layernorm_fwd_bf16", "vb_layernorm_bwd_bf16_workspace",
-               "vb_layernorm_bwd_bf16"]
+               "vb_layernorm_bwd_bf16",
+               # round 6: whole-layer launchers (csrc/layers.hip)
+               "vb_layer_fwd", "vb_layer_bwd"]
 
 
 def test_library_exports_every_declared_symbol(native):
@@ -53,7 +55,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 16
+    assert lib.vb_abi_version() == 17
     prev = native.set_gemm_mode("bf16x6")
     assert native.set_gemm_mode(prev) == "bf16x6" and native.set_gemm_mode(prev) == prev
     assert lib.vb_error_string(0) == b"ok"
@@ -69,7 +71,10 @@ def test_struct_layouts_match_the_header(native):
                            ("vb_linear_bwd_input_args", native.LinearBwdInputArgs),
                            ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs),
                            ("vb_linear_fp8_args", native.LinearFp8Args), ("vb_linear_mx_args", native.LinearMxArgs), ("vb_attention_mx_args", native.AttentionMxArgs),
-                           ("vb_adamw_tensor", native.AdamWTensor), ("vb_concap_batch", native.ConcapBatch)):
+                           ("vb_adamw_tensor", native.AdamWTensor), ("vb_concap_batch", native.ConcapBatch),
+                           ("vb_layer_linear", native.LayerLinear), ("vb_layer_norm", native.LayerNormP),
+                           ("vb_ffn_block", native.FfnBlock), ("vb_attn_block", native.AttnBlock),
+                           ("vb_layer_args", native.LayerArgs)):
         body = dict((n, b) for b, n in re.findall(r"typedef struct \{([^}]*)\} (\w+);", text))[struct]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -90,6 +95,9 @@ def test_argument_errors_do_not_need_a_gpu(native):
     assert lib.vb_attention_bwd(None, None, None) == -1
     assert lib.vb_linear_bwd_input(None, None) == -1 and lib.vb_linear_bwd_weight(None, None) == -1
     assert lib.vb_concap_finish_batch(None, None) == -1
+    assert lib.vb_layer_fwd(None, None) == -1 and lib.vb_layer_bwd(None, None) == -1
+    empty = native.LayerArgs()
+    assert lib.vb_layer_fwd(None, ctypes.byref(empty)) == -1          # neither an attention block nor an output + FFN block
     assert lib.vb_linear_fwd_mx(None, None) == -1 and lib.vb_quantize_rows_mx(None, 0, 0, None, 0, None, 0, None, 0) == -1 \
         and lib.vb_quantize_rows_mx_bf16(None, 0, 0, None, 0, None, 0, None, 0) == -1
     assert lib.vb_xent_fwd(None, 1, 0, None, 0, None, -1, None, None, None, None) == -1

@@ -367,7 +367,7 @@ def test_fixed_layers_run_without_grad_and_train_the_rest():
     assert model.bert.v_embeddings.image_embeddings.weight.grad is not None
 
 
-def test_gradient_side_dropout_rides_on_the_layernorm_backward():
+def test_gradient_side_dropout_rides_on_the_layernorm_backward(per_op_path):
     """Round 3: the dropout mask of the dense layer in front of a LayerNorm is applied by the LayerNorm backward kernel
     itself (vb_layernorm_bwd_drop) and handed to the dense node through a tensor tag. With dropout ON: (a) the
     stand-alone vb_dropout launches of backward all but disappear, (b) every gradient is BIT-identical to the path

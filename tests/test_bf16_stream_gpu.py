@@ -204,7 +204,7 @@ NAMES = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_ma
          "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
 
 
-def test_model_runs_its_encoder_on_the_bf16_kernels(bf16_mode, monkeypatch):
+def test_model_runs_its_encoder_on_the_bf16_kernels(bf16_mode, monkeypatch, per_op_path):
     """bert_base_2layer_2conect, the train_concap shapes (T = 36, R = 37): which launcher serves which linear, what dtype the
     hidden states have, that forward + backward run without a single fp32 encoder GEMM, and that an AdamW step refreshes the
     shadows."""
@@ -307,7 +307,7 @@ def test_bf16_stream_forward_drift_and_gradient_error_are_reported(bf16_mode):
     assert median > 1e-6
 
 
-def test_two_hundred_bf16_steps_track_the_fp32_oracle_loss_curve(bf16_mode):
+def test_two_hundred_bf16_steps_track_the_fp32_oracle_loss_curve(bf16_mode, per_op_path):
     """tests/test_loss_curve_gpu.py's experiment in the bf16 mode, on a small two-stream model whose widths the bf16 kernels
     serve (256-wide streams, 64 / 128-wide heads): 200 AdamW steps on 8 fixed batches, dropout off, against the fp32 CPU
     oracle (autograd + oracle/adamw_oracle.py). bf16 rounding noise feeds back through 200 steps: window means within 5 %."""

@@ -106,6 +106,77 @@ class WgradBf16Args(ctypes.Structure):
     ]
 
 
+class LayerLinear(ctypes.Structure):
+    """vb_layer_linear"""
+    _fields_ = [
+        ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("w", _c_f32p * VB_MAX_SEGMENTS),
+        ("bias", _c_f32p * VB_MAX_SEGMENTS),
+        ("w16", ctypes.c_void_p),
+        ("wt16", ctypes.c_void_p),
+        ("dw", _c_f32p * VB_MAX_SEGMENTS),
+        ("dbias", _c_f32p * VB_MAX_SEGMENTS),
+    ]
+
+
+class LayerNormP(ctypes.Structure):
+    """vb_layer_norm"""
+    _fields_ = [("gamma", _c_f32p), ("beta", _c_f32p), ("dgamma", _c_f32p), ("dbeta", _c_f32p)]
+
+
+class FfnBlock(ctypes.Structure):
+    """vb_ffn_block"""
+    _fields_ = [
+        ("M", ctypes.c_int64),
+        ("Hc", ctypes.c_int32), ("H", ctypes.c_int32), ("I", ctypes.c_int32),
+        ("ctx", ctypes.c_void_p),
+        ("x", ctypes.c_void_p),
+        ("o", LayerLinear), ("f1", LayerLinear), ("f2", LayerLinear),
+        ("ln1", LayerNormP), ("ln2", LayerNormP),
+        ("eps", ctypes.c_float), ("p_o", ctypes.c_float), ("p_f", ctypes.c_float),
+        ("seed_o", ctypes.c_uint64), ("seed_f", ctypes.c_uint64),
+        ("sum1", ctypes.c_void_p), ("a1", ctypes.c_void_p), ("h", ctypes.c_void_p), ("dact", ctypes.c_void_p),
+        ("sum2", ctypes.c_void_p), ("y", ctypes.c_void_p),
+        ("mean1", _c_f32p), ("rstd1", _c_f32p), ("mean2", _c_f32p), ("rstd2", _c_f32p),
+        ("dy", ctypes.c_void_p),
+        ("d_sum2", ctypes.c_void_p), ("d_sum2_drop", ctypes.c_void_p), ("d_pre", ctypes.c_void_p), ("d_a1", ctypes.c_void_p),
+        ("d_sum1", ctypes.c_void_p), ("d_sum1_drop", ctypes.c_void_p), ("d_ctx", ctypes.c_void_p),
+        ("ln_ws", _c_f32p),
+    ]
+
+
+class AttnBlock(ctypes.Structure):
+    """vb_attn_block"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("heads", ctypes.c_int32), ("head_dim", ctypes.c_int32),
+        ("n1", ctypes.c_int32), ("n2", ctypes.c_int32),
+        ("x1", ctypes.c_void_p), ("x2", ctypes.c_void_p),
+        ("mask1", _c_f32p), ("mask2", _c_f32p),
+        ("qkv1", LayerLinear), ("qkv2", LayerLinear),
+        ("p1", ctypes.c_float), ("p2", ctypes.c_float),
+        ("seed1", ctypes.c_uint64), ("seed2", ctypes.c_uint64),
+        ("qkv1_out", ctypes.c_void_p), ("qkv2_out", ctypes.c_void_p),
+        ("lse1", _c_f32p), ("lse2", _c_f32p),
+        ("ctx1", ctypes.c_void_p), ("ctx2", ctypes.c_void_p),
+        ("d_ctx1", ctypes.c_void_p), ("d_ctx2", ctypes.c_void_p),
+        ("dqkv1", ctypes.c_void_p), ("dqkv2", ctypes.c_void_p),
+        ("dvec", _c_f32p),
+        ("dres1", ctypes.c_void_p), ("dres2", ctypes.c_void_p),
+        ("dx1", ctypes.c_void_p), ("dx2", ctypes.c_void_p),
+    ]
+
+
+class LayerArgs(ctypes.Structure):
+    """vb_layer_args"""
+    _fields_ = [
+        ("dtype", ctypes.c_int32), ("training", ctypes.c_int32),
+        ("wgrad_stream", ctypes.c_void_p),
+        ("attn", AttnBlock),
+        ("s1", FfnBlock),
+        ("s2", FfnBlock),
+    ]
+
+
 class AttentionMxArgs(ctypes.Structure):
     """vb_attention_mx_args"""
     _fields_ = [
@@ -259,6 +330,8 @@ SIGNATURES = {
     "vb_layernorm_fwd_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _F32, _P, _P, _P]),
     "vb_layernorm_bwd_bf16_workspace": (_I64, [_I64, _I32]),
     "vb_layernorm_bwd_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _U64]),
+    "vb_layer_fwd": (ctypes.c_int, [_P, ctypes.POINTER(LayerArgs)]),
+    "vb_layer_bwd": (ctypes.c_int, [_P, ctypes.POINTER(LayerArgs)]),
 }
 
 _lib = None
@@ -276,7 +349,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 16:
+        if handle.vb_abi_version() != 17:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") in ("fp8", "mxfp8"):

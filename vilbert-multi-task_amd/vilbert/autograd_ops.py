@@ -38,9 +38,10 @@ def next_seed():
 #   * dy / x are record_stream()ed on the side stream (autograd may free them as soon as the node returns).
 # VB_WGRAD_STREAM=0 disables it.
 # ---------------------------------------------------------------------------------------------------------------
+import collections as _collections
 import os as _os
 
-_WGRAD = {"on": _os.environ.get("VB_WGRAD_STREAM", "1") != "0", "streams": {}, "used": {}}
+_WGRAD = {"on": _os.environ.get("VB_WGRAD_STREAM", "1") != "0", "streams": {}, "used": {}, "held": {}}
 
 
 def set_wgrad_stream(on):
@@ -73,6 +74,29 @@ def join_wgrad_streams(into=None, clear=False):
         cur.wait_stream(st)
     if clear:
         mine.clear()
+        for q in _WGRAD["held"].values():
+            q.clear()
+
+
+def hold_for_side_stream(ws, *tensors):
+    """A gradient tensor that a weight-gradient launch on side stream `ws` still READS and that the same backward node hands
+    back to autograd (the skip-connection gradient passing through a dense + residual node) must not be updated in place
+    while that launch is pending - and autograd's input buffers do exactly that (`old += new`) when they hold the only
+    reference to the first arrival. The stream order of the in-place add covers the node's own stream, not its side
+    stream (seen as a rare wrong dW with two processes time-slicing one GPU: tests/test_ddp_two_ranks_one_gpu.py, round
+    6). A second reference, kept until the launch has finished (event on `ws`; under stream capture: until the end of the
+    pass), sends the engine down its out-of-place path."""
+    q = _WGRAD["held"].get(ws.cuda_stream)
+    if q is None:
+        q = _WGRAD["held"][ws.cuda_stream] = _collections.deque()
+    if torch.cuda.is_current_stream_capturing():
+        q.append((None, tensors))
+        return
+    ev = torch.cuda.Event()
+    ev.record(ws)
+    q.append((ev, tensors))
+    while q and q[0][0] is not None and q[0][0].query():
+        q.popleft()
 
 
 _arena.END_PASS_HOOKS.append(lambda: join_wgrad_streams(clear=True))
@@ -130,6 +154,7 @@ def _wgrad(dy, x, weights, biases_present, need_w, need_b, launcher=None):
         dy.record_stream(ws)
         x.record_stream(ws)
         _WGRAD["used"].setdefault(dy.device.index, {})[ws.cuda_stream] = ws
+        hold_for_side_stream(ws, dy)     # (dy may also be on its way back to autograd as the residual's gradient)
     else:
         dws, dbs = launcher(dy, x, nseg, seg_n, need_b, dw_out=cw.views(), db_out=cb.views())
     return ([cw.out(s, dws[s]) if need_w[s] else None for s in range(nseg)],

@@ -26,6 +26,7 @@ import torch.nn.functional as TF
 
 from . import _native
 from . import functional as F
+from . import layers
 from . import ops
 from .utils import PreTrainedModel
 
@@ -354,6 +355,12 @@ class BertLayer(nn.Module):
         self.output = BertOutput(config)
 
     def forward(self, hidden_states, attention_mask):
+        # one autograd node / one call across the C ABI for the whole layer (layers.py, csrc/layers.hip) ...
+        y = layers.self_layer(self, hidden_states, attention_mask, _drop_p(self.attention.self.dropout),
+                              _drop_p(self.attention.output.dropout), _drop_p(self.output.dropout))
+        if y is not None:
+            return y, None
+        # ... or op by op (attention maps wanted, fp8 / MX inference, shapes the launcher does not take)
         attention_output, attention_probs = self.attention(hidden_states, attention_mask)
         return _ffn(self.intermediate, self.output, attention_output), attention_probs
 
@@ -436,6 +443,10 @@ class BertImageLayer(nn.Module):
         self.output = BertImageOutput(config)
 
     def forward(self, hidden_states, attention_mask, txt_embedding, txt_attention_mask):
+        y = layers.self_layer(self, hidden_states, attention_mask, _drop_p(self.attention.self.dropout),
+                              _drop_p(self.attention.output.dropout), _drop_p(self.output.dropout))
+        if y is not None:
+            return y, None
         attention_output, attention_probs = self.attention(hidden_states, attention_mask, txt_embedding,
                                                            txt_attention_mask)
         return _ffn(self.intermediate, self.output, attention_output), attention_probs
@@ -529,6 +540,13 @@ class BertConnectionLayer(nn.Module):
 
     def forward(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask=None,
                 use_co_attention_mask=False):
+        bi, bo_ = self.biattention, self.biOutput
+        out = layers.connection_layer(self, input_tensor1, attention_mask1, input_tensor2, attention_mask2,
+                                      (_drop_p(bi.dropout1), _drop_p(bi.dropout2), _drop_p(bo_.dropout1),
+                                       _drop_p(self.v_output.dropout), _drop_p(bo_.dropout2), _drop_p(self.t_output.dropout)),
+                                      _concurrent)
+        if out is not None:
+            return out[0], out[1], None
         bi_output1, bi_output2, co_attention_probs = self.biattention(
             input_tensor1, attention_mask1, input_tensor2, attention_mask2, co_attention_mask,
             use_co_attention_mask)
