@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VB_ABI_VERSION 17
+#define VB_ABI_VERSION 18
 
 /* argument errors (negative) */
 #define VB_E_BADARG   (-1)  /* null pointer / non-positive size */
@@ -433,7 +433,16 @@ int vb_additive_mask(void* stream, int64_t n, const void* mask, int32_t mask_is_
  * vb_attention_bwd: given the same arguments (lse filled by the forward, probs ignored) and dO,
  * writes dQ / dK / dV (each element exactly once - they may be column slices of one fused gradient
  * buffer) and uses dvec [batch, heads, n_q] as scratch. Broadcast batches are not supported.
+ *
+ * More than VB_MAX_KEYS keys (round 6; stacked retrieval options under autograd, reference vilbert.py:1008-1040): the
+ * caller cuts the keys into chunks of <= VB_MAX_KEYS, passes `lse` = the log-sum-exp over ALL keys (the merge of the
+ * chunk forwards) and calls the backward per chunk twice: dvec_mode = VB_DVEC_ACCUMULATE adds this chunk's share of
+ * D = rowsum(P dP) to `dvec` (zeroed by the caller; nothing else is written), then dvec_mode = VB_DVEC_GIVEN computes
+ * this chunk's dK / dV and its share of dQ from the complete D (the caller sums the dQ shares).
  * ------------------------------------------------------------------------------------------ */
+#define VB_DVEC_COMPUTE 0
+#define VB_DVEC_ACCUMULATE 1
+#define VB_DVEC_GIVEN 2
 typedef struct {
     int32_t batch, heads, head_dim, n_q, n_k;
     int32_t q_batch, kv_batch;
@@ -455,6 +464,7 @@ typedef struct {
     float* dK;       int64_t lddk;
     float* dV;       int64_t lddv;
     float* dvec;
+    int32_t dvec_mode;   /* VB_DVEC_* (round 6): 0 = the whole backward of n_k <= VB_MAX_KEYS keys in one call */
 } vb_attention_grads;
 
 int vb_attention_fwd(void* stream, const vb_attention_args* a);
@@ -618,6 +628,7 @@ typedef struct {
     uint16_t* dV;
     int64_t lddv;
     float* dvec;
+    int32_t dvec_mode;   /* VB_DVEC_*, as in vb_attention_grads */
 } vb_attention_bf16_grads;
 
 int vb_attention_fwd_bf16(void* stream, const vb_attention_bf16_args* a);

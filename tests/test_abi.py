@@ -55,7 +55,7 @@ def test_library_exports_every_declared_symbol(native):
 
 def test_abi_version_and_error_strings(native):
     lib = native.lib()
-    assert lib.vb_abi_version() == 17
+    assert lib.vb_abi_version() == 18
     prev = native.set_gemm_mode("bf16x6")
     assert native.set_gemm_mode(prev) == "bf16x6" and native.set_gemm_mode(prev) == prev
     assert lib.vb_error_string(0) == b"ok"

@@ -1,8 +1,5 @@
 mkdir -p gpurun_out
-K="bert_base_2layer_2conect.json-False-ring"
-for v in 1 2 3 4 5; do
-env DBG_ALL=1 timeout 600 python -m pytest tests/test_ddp_two_ranks_one_gpu.py -x -q -s -k "$K" 2>&1 | grep -E "BAD|passed|failed|Error" | head -5
-done > gpurun_out/r06_ddp2_dbg.txt 2>&1
-cat gpurun_out/r06_ddp2_dbg.txt
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/r06_gpu_suite_b.txt
-cat gpurun_out/r06_gpu_suite_b.txt
+timeout 900 python -m pytest tests/test_attention_chunks.py tests/test_kernels_gpu.py -q -m gpu 2>&1 | tail -25 > gpurun_out/r06_attn_long_a.txt
+cat gpurun_out/r06_attn_long_a.txt
+B=64 VB_GEMM_MODE=bf16 timeout 300 python tools/aten_census.py 2>&1 | head -60 | cut -c1-200 > gpurun_out/r06_aten_census_bf16_b64.txt
+cat gpurun_out/r06_aten_census_bf16_b64.txt

@@ -95,6 +95,7 @@ struct AttnP {
     io_t* dK; long lddk;
     io_t* dV; long lddv;
     float* dvec;      // [batch, heads, n_q]  D = rowsum(P dP): pass 1 out, pass 2 in
+    int dvec_mode;    // VB_DVEC_*: key chunks of a longer sequence (pass 1: accumulate D only / take D as given)
 };
 
 template <int DS>
@@ -280,7 +281,13 @@ __global__ __launch_bounds__(256) void attn_q_kernel(const AttnP p_in) {
             }
         }
         dsum = group_sum(dsum);
-        if (g == 0 && qt * 16 + c < p.n_q) p.dvec[bh * p.n_q + qt * 16 + c] = dsum;
+        if (p.dvec_mode == VB_DVEC_ACCUMULATE) {
+            // one chunk of a longer key sequence: its share of D (launches of one stream: plain read-modify-write), no dQ yet
+            if (g == 0 && qt * 16 + c < p.n_q) p.dvec[bh * p.n_q + qt * 16 + c] += dsum;
+            return;
+        }
+        if (p.dvec_mode == VB_DVEC_GIVEN) dsum = p.dvec[bh * p.n_q + q_row];
+        else if (g == 0 && qt * 16 + c < p.n_q) p.dvec[bh * p.n_q + qt * 16 + c] = dsum;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
             if (kt < nkt)
@@ -956,7 +963,7 @@ int launch_kv_lds(hipStream_t st, const AttnP& p) {
 
 template <int D, bool BWD>
 int launch_q(hipStream_t st, const AttnP& p) {
-    if (use_lds_path(p)) return launch_q_lds<D, BWD>(st, p);
+    if (use_lds_path(p) && p.dvec_mode == VB_DVEC_COMPUTE) return launch_q_lds<D, BWD>(st, p);   // (key chunks: generic kernel)
     dim3 block(256), grid((unsigned)((p.total + 3) / 4));
     if (p.n_kt <= 3) hipLaunchKernelGGL((attn_q_kernel<D, 3, BWD>), grid, block, 0, st, p);
     else if (p.n_kt <= 8) hipLaunchKernelGGL((attn_q_kernel<D, 8, BWD>), grid, block, 0, st, p);
@@ -1040,10 +1047,12 @@ extern "C" int VB_ATTN_BWD(void* stream, const attn_args_t* a, const attn_grads_
     p.dO = gr->dO; p.lddo = gr->lddo;
     p.dQ = gr->dQ; p.lddq = gr->lddq; p.dK = gr->dK; p.lddk = gr->lddk; p.dV = gr->dV; p.lddv = gr->lddv;
     p.dvec = gr->dvec;
+    p.dvec_mode = gr->dvec_mode;
+    if (p.dvec_mode < VB_DVEC_COMPUTE || p.dvec_mode > VB_DVEC_GIVEN) return VB_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int e = 0;
     static const int fused = [] { const char* ev = getenv("VB_ATTN_FUSED_BWD"); return ev ? atoi(ev) : 1; }();
-    if (fused && use_lds_path(p) && (gr->lddq | gr->lddk | gr->lddv) % 4 == 0) {
+    if (p.dvec_mode == VB_DVEC_COMPUTE && fused && use_lds_path(p) && (gr->lddq | gr->lddk | gr->lddv) % 4 == 0) {
         // short sequences: the whole backward in one launch (K, V, Q, dO staged once)
         switch (a->head_dim) {
             case 32: return launch_bwd_fused_lds<32>(st, p);
@@ -1060,6 +1069,7 @@ extern "C" int VB_ATTN_BWD(void* stream, const attn_args_t* a, const attn_grads_
         default: return VB_E_RANGE;
     }
     if (e) return e;
+    if (p.dvec_mode == VB_DVEC_ACCUMULATE) return 0;
     p.total = (long)a->batch * a->heads * p.n_kt;
     switch (a->head_dim) {
         case 32: return launch_kv<32>(st, p);

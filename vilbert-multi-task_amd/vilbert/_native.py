@@ -212,6 +212,9 @@ class AttentionArgs(ctypes.Structure):
     ]
 
 
+DVEC_COMPUTE, DVEC_ACCUMULATE, DVEC_GIVEN = 0, 1, 2      # include/vilbert_hip.h VB_DVEC_*
+
+
 class AttentionGrads(ctypes.Structure):
     """vb_attention_grads (and vb_attention_bf16_grads)"""
     _fields_ = [
@@ -220,6 +223,7 @@ class AttentionGrads(ctypes.Structure):
         ("dK", _c_f32p), ("lddk", ctypes.c_int64),
         ("dV", _c_f32p), ("lddv", ctypes.c_int64),
         ("dvec", _c_f32p),
+        ("dvec_mode", ctypes.c_int32),
     ]
 
 
@@ -349,7 +353,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.vb_abi_version() != 17:
+        if handle.vb_abi_version() != 18:
             raise RuntimeError("libvilbert_hip.so ABI version mismatch")
         _lib = handle
         if os.environ.get("VB_GEMM_MODE") in ("fp8", "mxfp8"):

@@ -322,12 +322,12 @@ def dropout(x, p, residual=None):
     return DropoutFn.apply(x, residual, p)
 
 
-def _check_keys_for_backward(n_keys):
-    """More than ops.MAX_KEYS keys are served chunk by chunk in INFERENCE only (ops._attention_fwd_long); under autograd the
-    backward kernels would refuse much later (VB_E_RANGE inside backward()) - say so where the call is made."""
-    if n_keys > ops.MAX_KEYS:
-        raise RuntimeError("attention: %d keys under autograd - one launch (and its backward) serves at most %d keys; longer "
-                           "key sequences (stacked retrieval options, in_batch_pairs) are supported in inference (no_grad) only"
+def _check_keys_for_backward(n_keys, want_probs):
+    """More than ops.MAX_KEYS keys run chunk by chunk, forward and backward (ops._attention_fwd_long / _attention_bwd_long);
+    only the probabilities tensor (`visualization`) does not exist there - say so where the call is made."""
+    if n_keys > ops.MAX_KEYS and want_probs:
+        raise RuntimeError("attention: %d keys with attention maps - one launch serves at most %d keys, and the chunked path "
+                           "of longer key sequences (stacked retrieval options, in_batch_pairs) returns no probabilities"
                            % (n_keys, ops.MAX_KEYS))
 
 
@@ -337,7 +337,7 @@ class SelfAttnFn(Function):
     @staticmethod
     def forward(ctx, qkv, mask_add, heads, drop_p, want_probs):
         H = qkv.shape[-1] // 3
-        _check_keys_for_backward(qkv.shape[1])
+        _check_keys_for_backward(qkv.shape[1], want_probs)
         seed = next_seed() if drop_p > 0.0 else 0
         out, probs, lse = ops.attention_fwd(qkv[..., :H], qkv[..., H:2 * H], qkv[..., 2 * H:], mask_add, heads,
                                             want_probs, True, drop_p, seed)
@@ -370,7 +370,7 @@ class BiAttnFn(Function):
     @staticmethod
     def forward(ctx, qkv1, qkv2, mask1, mask2, heads, p1, p2, want_probs):
         H = qkv1.shape[-1] // 3
-        _check_keys_for_backward(max(qkv1.shape[1], qkv2.shape[1]))
+        _check_keys_for_backward(max(qkv1.shape[1], qkv2.shape[1]), want_probs)
         s1 = next_seed() if p1 > 0.0 else 0
         s2 = next_seed() if p2 > 0.0 else 0
         q1, k1, v1 = qkv1[..., :H], qkv1[..., H:2 * H], qkv1[..., 2 * H:]

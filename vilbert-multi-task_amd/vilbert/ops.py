@@ -770,36 +770,77 @@ def merge_attention_chunks(outs, lses, heads):
     return out.reshape(B, Sq, H), total
 
 
-def _attention_fwd_long(q, k, v, mask_add, heads, want_lse):
-    """More than MAX_KEYS keys (inference: stacked retrieval options, in_batch_pairs): one launch per chunk of <= MAX_KEYS
-    keys, merged with merge_attention_chunks (a few small torch ops - this is the rare path; the shapes of every task in
-    vilbert_tasks.yml fit one launch)."""
+def _key_chunks(Sk):
+    n_chunks = (Sk + MAX_KEYS - 1) // MAX_KEYS
+    step = (Sk + n_chunks - 1) // n_chunks
+    return [(c0, min(Sk, c0 + step)) for c0 in range(0, Sk, step)]
+
+
+def _chunk_seed(seed, c):
+    """Dropout seed of key chunk c (the keep mask is a function of (seed, element index inside the launch): every chunk needs
+    its own seed, and backward must find it again from the node's one saved seed)."""
+    return (int(seed) + c * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF if seed else 0
+
+
+def _attention_fwd_long(q, k, v, mask_add, heads, want_lse, drop_p=0.0, seed=0):
+    """More than MAX_KEYS keys (stacked retrieval options, in_batch_pairs): one launch per chunk of <= MAX_KEYS keys, merged
+    with merge_attention_chunks (a few small torch ops - this is the rare path; the shapes of every task in
+    vilbert_tasks.yml fit one launch). Dropout acts on the probabilities element by element, so the mask of a chunk
+    commutes with the chunk's weight in the merge: dropout(w_c P_c) = w_c dropout(P_c)."""
     Bk, Sk, _ = k.shape
     if mask_add is not None:
         mask_add = _contig(mask_add).reshape(Bk, Sk)
-    n_chunks = (Sk + MAX_KEYS - 1) // MAX_KEYS
-    step = (Sk + n_chunks - 1) // n_chunks
     outs, lses = [], []
-    for c0 in range(0, Sk, step):
-        c1 = min(Sk, c0 + step)
+    for c, (c0, c1) in enumerate(_key_chunks(Sk)):
         m = mask_add[:, c0:c1].contiguous() if mask_add is not None else None
-        o, _, l = attention_fwd(q, k[:, c0:c1].contiguous(), v[:, c0:c1].contiguous(), m, heads, False, True)
+        o, _, l = attention_fwd(q, k[:, c0:c1].contiguous(), v[:, c0:c1].contiguous(), m, heads, False, True, drop_p,
+                                _chunk_seed(seed, c))
         outs.append(o)
         lses.append(l)
     out, total = merge_attention_chunks(outs, lses, heads)
     return out, None, (total if want_lse else None)
 
 
+def _attention_bwd_long(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p, seed):
+    """Backward of _attention_fwd_long (round 6; reference vilbert.py:1008-1040 under autograd). `lse` is the log-sum-exp over
+    ALL keys, so P = exp(S - lse) inside a chunk launch is the chunk's part of the full softmax; what couples the chunks is
+    D = rowsum(P dP) over all keys: pass A adds every chunk's share into one buffer (VB_DVEC_ACCUMULATE), pass B hands the
+    complete D to every chunk (VB_DVEC_GIVEN) for its dK / dV and its share of dQ."""
+    B, Sq, H = d_out.shape
+    Bk, Sk, _ = k.shape
+    if mask_add is not None:
+        mask_add = _contig(mask_add).reshape(Bk, Sk)
+    chunks = _key_chunks(Sk)
+    parts = [(k[:, c0:c1].contiguous(), v[:, c0:c1].contiguous(),
+              mask_add[:, c0:c1].contiguous() if mask_add is not None else None) for c0, c1 in chunks]
+    dvec = torch.zeros(B, heads, Sq, dtype=torch.float32, device=q.device)
+    dq_c = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
+    for c, (kc, vc, mc) in enumerate(parts):
+        dkv = torch.empty(2, kc.shape[0], kc.shape[1], H, dtype=torch.float32, device=q.device)   # (not written in this mode)
+        attention_bwd(d_out, q, kc, vc, mc, heads, lse, dq_c, dkv[0], dkv[1], drop_p, _chunk_seed(seed, c), dvec=dvec,
+                      dvec_mode=N.DVEC_ACCUMULATE)
+    total = None
+    for c, ((c0, c1), (kc, vc, mc)) in enumerate(zip(chunks, parts)):
+        dkv = torch.empty(2, kc.shape[0], kc.shape[1], H, dtype=torch.float32, device=q.device)
+        dq_c = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
+        attention_bwd(d_out, q, kc, vc, mc, heads, lse, dq_c, dkv[0], dkv[1], drop_p, _chunk_seed(seed, c), dvec=dvec,
+                      dvec_mode=N.DVEC_GIVEN)
+        dk[:, c0:c1].copy_(dkv[0])
+        dv[:, c0:c1].copy_(dkv[1])
+        total = dq_c if total is None else total.add_(dq_c)
+    dq.copy_(total)
+
+
 def attention_fwd(q, k, v, mask_add, heads, want_probs=False, want_lse=False, drop_p=0.0, seed=0):
     """q: [Bq, Sq, H*] view, k/v: [Bk, Sk, H*] views (last dim contiguous, uniform row stride, e.g. column
     slices of a fused [q|k|v] projection); mask_add: [Bk, 1, 1, Sk] or [Bk, Sk] fp32 additive, or None.
     Bq / Bk may be 1 against a larger batch (broadcast). Returns (ctx [B, Sq, H], probs|None, lse|None).
-    More than MAX_KEYS keys: served chunk by chunk when neither probabilities nor dropout are wanted (inference)."""
+    More than MAX_KEYS keys: served chunk by chunk (no probabilities tensor there)."""
     if k.shape[1] > MAX_KEYS:
-        if want_probs or drop_p > 0.0:
-            raise RuntimeError("attention: %d keys - more than %d keys are served without dropout / probabilities only"
+        if want_probs:
+            raise RuntimeError("attention: %d keys - more than %d keys are served without the probabilities tensor only"
                                % (k.shape[1], MAX_KEYS))
-        return _attention_fwd_long(q, k, v, mask_add, heads, want_lse)
+        return _attention_fwd_long(q, k, v, mask_add, heads, want_lse, drop_p, seed)
     a, keep, (B, Sq, Sk, H) = _attn_args(q, k, v, mask_add, heads, drop_p, seed)
     out = torch.empty(B, Sq, H, dtype=torch.float32, device=q.device)
     probs = torch.empty(B, heads, Sq, Sk, dtype=torch.float32, device=q.device) if want_probs else None
@@ -861,8 +902,11 @@ def attention_fwd_mx(q, k, v, mask_add, heads):
     return out
 
 
-def attention_bwd(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p=0.0, seed=0):
-    """Writes dq / dk / dv (row-strided views, e.g. column slices of a fused gradient buffer) in place."""
+def attention_bwd(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p=0.0, seed=0, dvec=None, dvec_mode=0):
+    """Writes dq / dk / dv (row-strided views, e.g. column slices of a fused gradient buffer) in place.
+    dvec / dvec_mode: the two passes over key chunks of a longer sequence (_attention_bwd_long)."""
+    if k.shape[1] > MAX_KEYS:
+        return _attention_bwd_long(_contig(d_out), q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p, seed)
     a, keep, (B, Sq, Sk, H) = _attn_args(q, k, v, mask_add, heads, drop_p, seed)
     d_out = _contig(d_out)
     a.lse = N.dev_f32(lse, "attention lse")
@@ -871,8 +915,9 @@ def attention_bwd(d_out, q, k, v, mask_add, heads, lse, dq, dk, dv, drop_p=0.0, 
     g.dQ, g.lddq = N.dev_f32(dq, "attention dq"), dq.stride(1)
     g.dK, g.lddk = N.dev_f32(dk, "attention dk"), dk.stride(1)
     g.dV, g.lddv = N.dev_f32(dv, "attention dv"), dv.stride(1)
-    dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
-    g.dvec = dvec.data_ptr()
+    if dvec is None:
+        dvec = torch.empty(B, heads, Sq, dtype=torch.float32, device=q.device)
+    g.dvec, g.dvec_mode = N.dev_f32(dvec, "attention dvec"), dvec_mode
     N.check(N.lib().vb_attention_bwd(N.stream_ptr(), ctypes.byref(a), ctypes.byref(g)), "vb_attention_bwd")
 
 
