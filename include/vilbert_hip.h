@@ -669,6 +669,9 @@ typedef struct {
     float* dbias[VB_MAX_SEGMENTS];  /* [seg_n] each, ADDED into; NULL = no bias gradient for that segment */
     int64_t M, K;
     int32_t nseg, seg_n;
+    int32_t n_valid;                /* round 6: rows of dW / entries of dbias that EXIST (nseg == 1): seg_n is the tile-padded
+                                       width of dY (zero columns past n_valid), nothing past row n_valid is written; 0 = seg_n */
+    int32_t reserved;
 } vb_wgrad_bf16_args;
 
 int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a);
@@ -690,6 +693,8 @@ typedef struct {
 } vb_shadow_seg;
 int vb_weight_shadow_multi(void* stream, int32_t n_segs, const vb_shadow_seg* table, int64_t total_tiles);
 int vb_cast_f32_bf16(void* stream, int64_t n, const float* x, uint16_t* y);
+/* fp32 [rows][n] with row stride ldx -> bf16 [rows][ldy], the columns n .. ldy - 1 ZERO (ldx % 4 == 0, ldy % 8 == 0) */
+int vb_cast_rows_f32_bf16(void* stream, int64_t rows, int32_t n, const float* x, int64_t ldx, uint16_t* y, int64_t ldy);
 int vb_cast_bf16_f32(void* stream, int64_t n, const uint16_t* x, float* y);
 int vb_layernorm_fwd_bf16(void* stream, int64_t rows, int32_t n_cols, const uint16_t* x, const float* gamma, const float* beta,
                           float eps, uint16_t* y, float* mean, float* rstd);

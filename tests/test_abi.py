@@ -37,7 +37,7 @@ EXTRA_DECLS = ["vb_concap_finish_batch", "vb_xent_fwd", "vb_xent_bwd", "vb_kl_fw
                "vb_layernorm_bwd_workspace", "vb_text_embed_bwd", "vb_attention_bwd",
                # round 5: the bf16 training path (csrc/gemm_bf16.hip, rowops16.hip)
                "vb_attention_fwd_bf16", "vb_attention_bwd_bf16", "vb_linear_bf16", "vb_wgrad_bf16", "vb_colsum_bf16_workspace", "vb_colsum_bf16", "vb_weight_shadow_bf16", "vb_weight_shadow_multi",
-               "vb_cast_f32_bf16", "vb_cast_bf16_f32", "vb_layernorm_fwd_bf16", "vb_layernorm_bwd_bf16_workspace",
+               "vb_cast_f32_bf16", "vb_cast_rows_f32_bf16", "vb_cast_bf16_f32", "vb_layernorm_fwd_bf16", "vb_layernorm_bwd_bf16_workspace",
                "vb_layernorm_bwd_bf16",
                # round 6: whole-layer launchers (csrc/layers.hip)
                "vb_layer_fwd", "vb_layer_bwd"]

@@ -240,3 +240,92 @@ def test_bf16_step_at_the_timed_batch_losses_and_every_gradient_vs_the_oracle():
           % (len(rel), median, p90, worst, rel[-1][1], ", ".join("%s %.3f" % (n, e) for e, n in rel[-5:])))
     assert median <= 0.05 and p90 <= 0.15 and worst <= 0.25, (median, p90, worst)
     assert opt is not None
+
+
+@pytest.mark.parametrize("M,n,K,bias", [(1628, 30522, 768, True), (389, 30522, 768, True), (400, 4100, 1024, False),
+                                        (70, 30522, 768, True)])
+def test_ragged_weight_gradient_of_the_wide_heads_on_the_bf16_kernel(M, n, K, bias):
+    """Round 6 (review: "bf16 heads", reference vilbert.py:1178-1196): the weight gradient of an fp32-tensor linear whose width
+    is no tile multiple - the tied 30,522 x 768 MLM decoder at the labelled rows of B = 256 (1,628) and B = 64 (389) - runs on
+    wgrad_bf16_kernel over a bf16 copy of dY padded with zero columns to 30,720 (vb_cast_rows_f32_bf16); n_valid keeps every
+    store inside the 30,522 rows. Whole dW / db against float64 on the bf16-rounded operands, targets pre-filled (the kernel
+    adds), the gradient read through a PADDED row stride like the logits gradient is, guard rows behind dW untouched, two
+    runs bit-identical."""
+    from vilbert import _native, ops16
+    prev = _native.set_gemm_mode("bf16")
+    try:
+        ld = (n + 3) // 4 * 4 + 8
+        dy_store = _rand(M, ld, seed=M + n, scale=0.05)
+        dy = dy_store[:, :n]
+        dy_store[:, n:] = float("nan")                # what lies in the padding of the logits gradient must never be read
+        x = _rand(M, K, seed=K + M)
+        guard = 64
+        store = torch.full(((n + guard) * K,), 0.25, device=DEV)
+        dw = store[:n * K].view(n, K)
+        db0 = torch.full((n,), -0.5, device=DEV)
+        outs = []
+        for run in range(2):
+            store.fill_(0.25)
+            db = db0.clone()
+            ops16.linear_bwd_weight_ragged(dy, x, [bias], [dw], [db] if bias else None)
+            torch.cuda.synchronize()
+            outs.append((dw.clone(), db.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "two runs differ"
+        assert float((store[n * K:] - 0.25).abs().max()) == 0.0, "rows past n_valid were written"
+        dy64, x64 = dy.to(BF16).double(), x.to(BF16).double()
+        want = dy64.t() @ x64 + 0.25
+        mag = dy64.abs().t() @ x64.abs()
+        err = (outs[0][0].double() - want).abs()
+        tol = 3e-6 * mag + 1e-5
+        assert torch.isfinite(outs[0][0]).all() and not (err > tol).any(), "dW: worst err / tol %.2f" % float((err / tol).max())
+        if bias:
+            wantb = dy64.sum(0) - 0.5
+            errb = (outs[0][1].double() - wantb).abs()
+            assert not (errb > 3e-6 * dy64.abs().sum(0) + 1e-5).any(), "db: %.3e" % float(errb.max())
+        else:
+            assert torch.equal(outs[0][1], db0)
+    finally:
+        _native.set_gemm_mode(prev)
+
+
+def test_bf16_mode_sends_the_decoder_weight_gradient_to_the_bf16_kernel(monkeypatch):
+    """The model in the bf16 mode: the 30,522-wide decoder's weight gradient goes through linear_bwd_weight_ragged (counted),
+    and the tied word-embedding gradient stays within bf16 rounding of the fp32-tensor kernel's (VB_RAGGED off by patching)."""
+    from vilbert import _native, ops16
+    from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    sd = synth.make_state_dict(cfg, "pretraining")
+    names = ["input_ids", "image_feat", "image_loc", "token_type_ids", "attention_mask", "image_attention_mask",
+             "masked_lm_labels", "image_label", "image_target", "next_sentence_label"]
+    x = synth.make_inputs(cfg, 32, 36, 37, seed=11, with_labels=True)
+    args = [x[k].to(DEV) for k in names]
+    prev = _native.set_gemm_mode("bf16")
+    try:
+        calls = []
+        real = ops16.linear_bwd_weight_ragged
+
+        def counted(*a, **k):
+            calls.append(a[0].shape)
+            return real(*a, **k)
+
+        def grads(ragged):
+            monkeypatch.setattr(ops16, "linear_bwd_weight_ragged", counted)
+            monkeypatch.setattr(ops16, "ragged_wgrad_ok", (lambda *a: ragged and _native.bf16_stream() and a[1] % 128 == 0
+                                                           and a[0] >= 4096 and a[2] >= 64))
+            m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+            m.load_state_dict(sd)
+            m = m.to(DEV).eval()                     # (dropout off: the two runs see the same function)
+            sum(l.mean() for l in m(*args)).backward()
+            torch.cuda.synchronize()
+            return m.bert.embeddings.word_embeddings.weight.grad.clone(), m.cls.predictions.bias.grad.clone()
+        gw0, gb0 = grads(False)
+        assert not calls
+        gw1, gb1 = grads(True)
+        assert len(calls) == 1 and calls[0][-1] == cfg["vocab_size"], calls
+        relw = float((gw1.double() - gw0.double()).norm() / gw0.double().norm())
+        relb = float((gb1.double() - gb0.double()).norm() / gb0.double().norm())
+        print("decoder weight gradient, bf16 kernel vs fp32-tensor kernel (both on bf16-rounded operands): relative L2 %.2e, "
+              "bias %.2e" % (relw, relb))
+        assert relw <= 2e-3 and relb <= 2e-3
+    finally:
+        _native.set_gemm_mode(prev)

@@ -453,3 +453,29 @@ def test_kl_div_of_log_softmax_forward_backward(rows, n):
     (want * 0.6).backward()
     _close(loss, want.detach(), rtol=5e-6, atol=1e-6)
     _close(s.grad, s64.grad, rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("M,N,K", [(1628, 30522, 768), (2048, 30522, 768), (389, 30522, 768), (300, 8190, 256)])
+def test_decoder_input_gradient_is_split_along_the_contraction_in_the_bf16_operand_modes(M, N, K):
+    """Round 6: the small-output / long-contraction input gradient (the MLM decoder: dX [rows x 768] over 30,522 out-features)
+    is cut along K in the bf16-operand modes as it is in fp32 (it ran unsplit on 96 blocks there: 0.90 ms of the 27 ms bf16
+    step at B = 256, 0.36 ms split). Against float64 on the bf16-rounded operands, through a padded row stride with NaN in
+    the padding; two runs bit-identical (ordered reduce through the deterministic workspace)."""
+    from vilbert import _native, ops
+    prev = _native.set_gemm_mode("bf16")
+    try:
+        w = _rand(N, K, seed=2, scale=0.05)
+        dy_buf = torch.full((M, (N + 3) // 4 * 4), float("nan"))
+        dy_buf[:, :N] = _rand(M, N, seed=4)
+        dy = dy_buf.cuda()[:, :N]
+        wd = w.cuda()
+        dx1 = ops.linear_bwd_input(dy, [wd], K).clone()
+        dx2 = ops.linear_bwd_input(dy, [wd], K)
+        assert torch.equal(dx1, dx2), "two runs differ"
+        want = dy_buf[:, :N].bfloat16().double() @ w.bfloat16().double()
+        mag = dy_buf[:, :N].bfloat16().double().abs() @ w.bfloat16().double().abs()
+        err = (dx1.cpu().double() - want).abs()
+        tol = 3e-6 * mag + 1e-5
+        assert not (err > tol).any(), "worst err / tol %.2f" % float((err / tol).max())
+    finally:
+        _native.set_gemm_mode(prev)

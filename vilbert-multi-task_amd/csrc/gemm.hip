@@ -1009,16 +1009,27 @@ extern "C" int vb_linear_bwd_input(void* stream, const vb_linear_bwd_input_args*
         // A small output with a long contraction (the MLM decoder: dX [1628 x 768] over 30522 out-features = 136 tiles
         // for 256 CUs, 66 TF) is cut along K as the wgrad launches are: the planner picks the split count and the splits
         // add into dX with atomics (dX is zero-filled first unless it already holds a contribution).
+        // (round 6: in the bf16-operand modes too - the bf16 training mode left this one launch unsplit on 96 blocks:
+        // 0.90 ms of its 27 ms step at B = 256, profiles/r06_bf16_ragged_wgrad_ab.txt; there the count is chosen here:
+        // about three blocks per CU, at least 1024 contraction elements per split)
         const bool split_k = p.mul == nullptr && p.R == nullptr && (long)p.M * p.N <= 2048L * 1024 && p.K >= 4096 &&
-                             (p.epi == EPI_STORE || p.epi == EPI_ACCUM) && gemm_mode() == 0;
+                             (p.epi == EPI_STORE || p.epi == EPI_ACCUM);
         auto launch_main = [&](GemmP q, bool vq) -> int {
             if (!split_k) return launch_gemm<true, false>(st, q, vq, 1);
+            int planes_splits = 1;
+            if (gemm_mode() != 0) {
+                const long tiles = (long)((q.M + 127) / 128) * ((q.N + 127) / 128);
+                long sp = (768 + tiles - 1) / tiles;
+                if (sp > q.K / 1024) sp = q.K / 1024;
+                planes_splits = (int)(sp < 1 ? 1 : (sp > 32 ? 32 : sp));
+                if (planes_splits == 1) return launch_gemm<true, false>(st, q, vq, 1);
+            }
             if (q.epi == EPI_STORE) {
                 if (int e = zero_rows(st, q.C[0], q.ldc, q.M, q.N)) return e;       // (a kernel, not a memset node: see zero_rows)
             }
             q.epi = EPI_ACCUM;
             q.accumulate = 1;
-            return launch_gemm<true, false>(st, q, vq, -1);
+            return launch_gemm<true, false>(st, q, vq, -1, planes_splits);
         };
         const int k_main = p.K / V2_BK * V2_BK;
         if (fused && a->nseg == 1 && k_main >= 256 && k_main != p.K && p.R == nullptr && p.mul == nullptr &&

@@ -447,6 +447,7 @@ struct HwP {
     // consecutive addresses - and its bias-gradient partial to ws_b + split N; wgrad_bf16_reduce_kernel adds the splits in
     // order into dW / db. nullptr = fp32 atomics straight into dW / db (run-to-run differences in the last bits).
     float* ws; float* ws_b;
+    int n_valid;                    // rows of a segment's dW (and entries of its db) that exist: the tiles cover cseg >= n_valid rows
 };
 
 // unit of block `b` in its i-th round: the 32 blocks of an XCD (b % 8) take CONSECUTIVE units - the same contraction split and
@@ -719,19 +720,22 @@ __global__ __launch_bounds__(HB_THREADS) void wgrad_bf16_kernel(const HwP p) {
             }
             continue;
         }
-        float* __restrict__ cb = p.C[seg] + (long)(n0 - seg * p.cseg + wm * 64 + 4 * hi) * p.ldc + k0 + wn * 64 + l31;
+        const int nl0 = n0 - seg * p.cseg + wm * 64 + 4 * hi;       // this lane's first row inside the segment
+        float* __restrict__ cb = p.C[seg] + (long)nl0 * p.ldc + k0 + wn * 64 + l31;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr)
-                    unsafeAtomicAdd(cb + (long)(32 * i + (rr & 3) + 8 * (rr >> 2)) * p.ldc + 32 * j, acc[i][j][rr]);
+                    if (nl0 + 32 * i + (rr & 3) + 8 * (rr >> 2) < p.n_valid)
+                        unsafeAtomicAdd(cb + (long)(32 * i + (rr & 3) + 8 * (rr >> 2)) * p.ldc + 32 * j, acc[i][j][rr]);
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float t = bsum[i] + __shfl_xor(bsum[i], 32);
-                if (hi == 0) unsafeAtomicAdd(p.bias[seg] + (n0 - seg * p.cseg + wm * 64 + 32 * i + l31), t);
+                if (hi == 0 && n0 - seg * p.cseg + wm * 64 + 32 * i + l31 < p.n_valid)
+                    unsafeAtomicAdd(p.bias[seg] + (n0 - seg * p.cseg + wm * 64 + 32 * i + l31), t);
                 bsum[i] = 0.f;
             }
         }
@@ -753,15 +757,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const HwP p) {
         for (int s = 1; s < p.splits; ++s) a += w[(long)s * n4];
         const int n0 = (t / p.tiles_k) * HB_BM, k0 = (t % p.tiles_k) * HB_BN;
         const int seg = n0 / p.cseg;
-        float* __restrict__ c = p.C[seg] + (long)(n0 - seg * p.cseg + wm * 64 + 32 * i + 4 * hi + 8 * qq) * p.ldc + k0 + wn * 64 +
-                                32 * j + l31;
+        const int row = n0 - seg * p.cseg + wm * 64 + 32 * i + 4 * hi + 8 * qq;
+        float* __restrict__ c = p.C[seg] + (long)row * p.ldc + k0 + wn * 64 + 32 * j + l31;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c[(long)e * p.ldc] += a[e];
+        for (int e = 0; e < 4; ++e)
+            if (row + e < p.n_valid) c[(long)e * p.ldc] += a[e];
     } else {
         const long n = idx - n4;
         if (n >= p.N) return;
         const int seg = (int)(n / p.cseg);
-        if (p.bias[seg] == nullptr) return;
+        if (p.bias[seg] == nullptr || n - (long)seg * p.cseg >= p.n_valid) return;
         float a = p.ws_b[n];
         for (int s = 1; s < p.splits; ++s) a += p.ws_b[(long)s * p.N + n];
         p.bias[seg][n - (long)seg * p.cseg] += a;
@@ -781,6 +786,31 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(long n8, const float
     } else if (i == n8) {
         for (long e = 8 * n8; e < n; ++e) y[e] = bf16_rne(x[e]);
     }
+}
+
+// fp32 [rows][n] (row stride ldx) -> bf16 [rows][ldy], columns n .. ldy - 1 zero-filled: the padded bf16 operand of a weight
+// gradient whose output width is not a tile multiple (the 30,522-wide MLM decoder: 30,720 = 120 x 256)
+__global__ __launch_bounds__(256) void cast_rows_f32_bf16_kernel(long rows, int n, const float* __restrict__ x, long ldx,
+                                                                 unsigned short* __restrict__ y, long ldy) {
+    const long chunks = ldy / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * chunks) return;
+    const long r = i / chunks;
+    const int c = (int)(i % chunks) * 8;
+    const float* __restrict__ xp = x + r * ldx + c;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (c + 8 <= n) {
+        a = *reinterpret_cast<const f32x4*>(xp);
+        b = *reinterpret_cast<const f32x4*>(xp + 4);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e < n) a[e] = xp[e];
+            if (c + 4 + e < n) b[e] = xp[4 + e];
+        }
+    }
+    *reinterpret_cast<v4i*>(y + r * ldy + c) = v4i{(int)pack_bf16(a[0], a[1]), (int)pack_bf16(a[2], a[3]), (int)pack_bf16(b[0], b[1]),
+                                                   (int)pack_bf16(b[2], b[3])};
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(long n8, const unsigned short* __restrict__ x, float* __restrict__ y,
@@ -963,6 +993,8 @@ extern "C" int vb_wgrad_bf16(void* stream, const vb_wgrad_bf16_args* a) {
         p.bias[s] = a->dbias[s];
     }
     p.ldc = a->ldw; p.cseg = a->seg_n;
+    if (a->n_valid < 0 || a->n_valid > a->seg_n || (a->n_valid != 0 && a->n_valid != a->seg_n && a->nseg != 1)) return VB_E_BADARG;
+    p.n_valid = a->n_valid > 0 ? a->n_valid : a->seg_n;
     p.tiles_k = p.K / HB_BN;
     p.tiles = (p.N / HB_BM) * p.tiles_k;
     p.nkt = (p.M + HB_BK - 1) / HB_BK;
@@ -1026,6 +1058,16 @@ extern "C" int vb_cast_f32_bf16(void* stream, int64_t n, const float* x, uint16_
     const long n8 = n / 8;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        n8, x, y, (long)n);
+    VB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vb_cast_rows_f32_bf16(void* stream, int64_t rows, int32_t n, const float* x, int64_t ldx, uint16_t* y, int64_t ldy) {
+    if (x == nullptr || y == nullptr || rows <= 0 || n <= 0 || ldx < n || ldy < n) return VB_E_BADARG;
+    if (ldx % 4 != 0 || ldy % 8 != 0 || !vb_aligned16(x) || !vb_aligned16(y)) return VB_E_ALIGN;
+    const long work = rows * (ldy / 8);
+    hipLaunchKernelGGL(cast_rows_f32_bf16_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (long)rows, (int)n, x, (long)ldx, y, (long)ldy);
     VB_LAUNCH_CHECK();
     return 0;
 }

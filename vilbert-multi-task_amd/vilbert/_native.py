@@ -103,6 +103,7 @@ class WgradBf16Args(ctypes.Structure):
         ("dbias", _c_f32p * VB_MAX_SEGMENTS),
         ("M", ctypes.c_int64), ("K", ctypes.c_int64),
         ("nseg", ctypes.c_int32), ("seg_n", ctypes.c_int32),
+        ("n_valid", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -330,6 +331,7 @@ SIGNATURES = {
     "vb_weight_shadow_bf16": (ctypes.c_int, [_P, _I32, _I32, _P, _I64, _P, _I64, _P, _I64]),
     "vb_weight_shadow_multi": (ctypes.c_int, [_P, _I32, _P, _I64]),
     "vb_cast_f32_bf16": (ctypes.c_int, [_P, _I64, _P, _P]),
+    "vb_cast_rows_f32_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _I64, _P, _I64]),
     "vb_cast_bf16_f32": (ctypes.c_int, [_P, _I64, _P, _P]),
     "vb_layernorm_fwd_bf16": (ctypes.c_int, [_P, _I64, _I32, _P, _P, _P, _F32, _P, _P, _P]),
     "vb_layernorm_bwd_bf16_workspace": (_I64, [_I64, _I32]),

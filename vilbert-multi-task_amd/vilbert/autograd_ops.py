@@ -201,7 +201,12 @@ class LinearFn(Function):
         dws, dbs = [None] * nseg, [None] * nseg
         if any(need_w) or any(need_b):
             # (the fused launch computes every segment; segments nobody asked for land in scratch buffers)
-            dws, dbs = _wgrad(dpre, x, weights, biases, need_w, need_b)
+            launcher = None
+            if nseg == 1 and dpre.is_cuda and ops16.ragged_wgrad_ok(seg_n, K, dpre.numel() // max(seg_n, 1)):
+                # bf16 mode: the wide ragged heads (30,522-wide MLM decoder) on the bf16 weight-gradient kernel
+                launcher = lambda dy_, x_, nseg_, seg_n_, want_b, dw_out=None, db_out=None: \
+                    ops16.linear_bwd_weight_ragged(dy_, x_, want_b, dw_out, db_out)
+            dws, dbs = _wgrad(dpre, x, weights, biases, need_w, need_b, launcher)
         return (dx, dres, None, None, None) + tuple(dws) + tuple(dbs)
 
 

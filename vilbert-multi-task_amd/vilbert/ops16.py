@@ -9,6 +9,7 @@ parameter changes (torch's version counter, or the native optimizer's `weights_c
 captured graphs keep their addresses).
 """
 import ctypes
+import os
 import math
 import weakref
 
@@ -289,6 +290,57 @@ def linear_bwd_weight(dy, x, nseg, seg_n, want_bias, dw_out=None, db_out=None):
     ops._timed(lambda: N.check(N.lib().vb_wgrad_bf16(N.stream_ptr(), ctypes.byref(a)), "vb_wgrad_bf16"),
                2.0 * M * n * K, ("wgrad16", M, seg_n, K, nseg))
     return dws, dbs
+
+
+# opt-in (VB_BF16_RAGGED_WGRAD=1): measured on one box, B = 256: the decoder's weight gradient 0.326 ms on the fp32-tensor kernel
+# -> 0.191 ms here + ~0.1 ms of casts, the step unchanged within 0.4 % (profiles/r06_bf16_ragged_wgrad_ab.txt)
+_RAGGED_WGRAD = os.environ.get("VB_BF16_RAGGED_WGRAD", "0") == "1"
+
+
+def ragged_wgrad_ok(n_out, K, rows):
+    """The weight gradient of an fp32-tensor linear whose width is NOT a tile multiple (the MLM decoder: 30,522 x 768) on the
+    bf16 weight-gradient kernel (linear_bwd_weight_ragged): in the bf16 mode, for outputs wide enough to pay for the two casts."""
+    return _RAGGED_WGRAD and N.bf16_stream() and K % 128 == 0 and n_out >= 4096 and rows >= 64
+
+
+def linear_bwd_weight_ragged(dy, x, want_bias, dw_out=None, db_out=None):
+    """dW += dY^T X, db += colsum(dY) for ONE fp32-tensor linear of any output width n (round 6: the heads of the bf16 mode,
+    reference vilbert.py:1178-1196 - the tied 30,522 x 768 decoder was 3.4 % (B = 256) ... 7.7 % (B = 64) of the bf16 step on
+    the fp32-tensor kernel). dy fp32 [rows, n] (row-strided view allowed), x fp32 [rows, K]: both are rounded to bf16 - what
+    the fp32-tensor kernel of this mode does with its operands too - dy into a buffer padded with ZERO columns to a
+    multiple of 256, and vb_wgrad_bf16 writes rows < n only (n_valid). Same contract as ops.linear_bwd_weight (nseg = 1)."""
+    N.ensure_deterministic(dy.device)
+    n, K = dy.shape[-1], x.shape[-1]
+    dy2 = dy.reshape(-1, n) if dy.dim() != 2 else dy
+    x2 = ops._contig(x).reshape(-1, K)
+    M = x2.shape[0]
+    if dy2.shape[0] != M:
+        raise RuntimeError("linear_bwd_weight: row count mismatch")
+    if dy2.stride(1) != 1 or dy2.stride(0) % 4 != 0:
+        dy2 = dy2.contiguous() if n % 4 == 0 else torch.nn.functional.pad(dy2, (0, 4 - n % 4))[:, :n]
+    n_pad = (n + 255) // 256 * 256
+    dy16 = torch.empty(M, n_pad, dtype=BF16, device=dy.device)
+    N.check(N.lib().vb_cast_rows_f32_bf16(N.stream_ptr(), M, n, N.dev_f32(dy2, "linear grad_output"), dy2.stride(0),
+                                          dy16.data_ptr(), n_pad), "vb_cast_rows_f32_bf16")
+    x16 = cast_bf16(x2)
+    dw = dw_out[0] if dw_out is not None and dw_out[0] is not None else None
+    db = db_out[0] if db_out is not None and db_out[0] is not None else None
+    if dw is None:
+        dw = torch.zeros(n, K, dtype=torch.float32, device=dy.device)
+    elif dw.shape != (n, K) or not dw.is_contiguous():
+        raise RuntimeError("linear_bwd_weight: gradient target must be a contiguous [n, K] tensor")
+    if want_bias[0] and db is None:
+        db = torch.zeros(n, dtype=torch.float32, device=dy.device)
+    a = N.WgradBf16Args()
+    a.dY, a.ldy, a.X, a.ldx = dy16.data_ptr(), n_pad, x16.data_ptr(), K
+    a.M, a.K, a.nseg, a.seg_n, a.ldw, a.n_valid = M, K, 1, n_pad, K, n
+    a.dW[0] = N.dev_f32(dw, "weight gradient")
+    a.dbias[0] = N.dev_f32(db, "bias gradient") if (want_bias[0] and db is not None) else None
+    ops._timed(lambda: N.check(N.lib().vb_wgrad_bf16(N.stream_ptr(), ctypes.byref(a)), "vb_wgrad_bf16"),
+               2.0 * M * n * K, ("wgrad16", M, n, K, 1))
+    # (on a weight-gradient side stream the caller has made that stream torch's current one: the two bf16 temporaries come
+    # from its allocator pool)
+    return [dw], [db if want_bias[0] else None]
 
 
 def layernorm_fwd(x, gamma, beta, eps, want_stats=False):
