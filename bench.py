@@ -396,9 +396,24 @@ def main():
                 "wgrad_bf16_kernel (ds_read_b64_tr_b16 fragments), v_mfma_f32_32x32x16_bf16, persistent 256x128 tiles: 8 MFMA + 4 "
                 "LDS-DMA loader waves per CU; the heads / poolers on gemm_planes_kernel (fp32 tensors, bf16 operands)",
                 "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                "launches_per_step": n, "traffic": None,
+                "launches_per_step": n, "traffic": bf16_traffic()[0], "traffic_note": bf16_traffic()[1],
                 "what": "all GEMM launches of one extra step (fwd + dgrad + wgrad), algorithmic 2MNK FLOPs / sum of HIP-event "
                         "durations (single stream); bf16 dense MFMA peak 2500 TF"}
+
+    def bf16_traffic():
+        """HBM-side bytes of the dominant bf16 symbol - the weight gradient, wgrad_bf16_kernel + its ordered reduce - at its
+        most frequent large shape, from the committed rocprofv3 PMC passes (profiles/r06_bf16_gemm_traffic.json)."""
+        tp = os.path.join(ROOT, "profiles", "r06_bf16_gemm_traffic.json")
+        if not os.path.isfile(tp):
+            return None, "not measured"
+        rows = [r for r in json.load(open(tp))["launches"] if r["kernel"] == "wgrad_bf16_kernel" and r["shape"] == "text FFN up"]
+        if not rows:
+            return None, "not measured"
+        r = rows[0]
+        tot = r.get("pair_hbm_bytes_corrected", r["hbm_bytes_corrected"])
+        return tot, ("rocprofv3 PMC, wgrad_bf16_kernel + wgrad_bf16_reduce_kernel (deterministic weight gradient) M=%d N=%d K=%d: "
+                     "%.0f MB per launch pair vs %.0f MB algorithmic; the q|k|v forward of gemm_bf16_kernel: 147 MB vs 60 MB "
+                     "(profiles/r06_gemm_pmc.txt)" % (r["M"], r["N"], r["K"], tot / 1e6, r["algorithmic_bytes"] / 1e6))
 
     def comm_model(step64_ms, mibs=(64, 256)):
         """(In the bf16 GEMM mode - switched on by the caller - the wrapper defaults to bf16 exchange buckets and the direct
@@ -945,7 +960,9 @@ def main():
                        "launches_per_forward": mx_n // 2, "avg_launch_us": round(1e3 * mx_ms / max(mx_n, 1), 2),
                        "what": "all linear launches of 2 forwards, algorithmic 2MNK / sum of HIP-event durations (single stream)",
                        "traffic": None}
-            tp = os.path.join(ROOT, "profiles", "r04_mx_gemm_traffic.json")
+            tp = os.path.join(ROOT, "profiles", "r06_mx_gemm_traffic.json")
+            if not os.path.isfile(tp):
+                tp = os.path.join(ROOT, "profiles", "r04_mx_gemm_traffic.json")
             if os.path.isfile(tp):
                 t0 = json.load(open(tp))["launches"][0]
                 mx_roof["traffic"] = t0["hbm_bytes_corrected"]
@@ -1070,7 +1087,6 @@ def main():
             if args.gemm_mode == "bf16":
                 line["dtype"] = BF16_DTYPE
                 line["roofline"].update(bf16_roofline(achieved, gemm_launches // prof_steps))
-                line["roofline"]["traffic_note"] = "not measured for this mode"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.mode)
         # the legs a reader needs first, again, as the LAST key: the driver keeps the final 8 KB of stdout

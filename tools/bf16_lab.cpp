@@ -351,7 +351,15 @@ static void time_all() {
     float* dWg;
     CK(hipMalloc(&dWg, (size_t)3072 * 3072 * 4));
     CK(hipMemset(dWg, 0, (size_t)3072 * 3072 * 4));
-    printf("---- vb_wgrad_bf16\n");
+    // the product default: deterministic weight gradient (partials to a registered workspace + ordered reduce); LAB_DET=0 = atomics
+    const char* det_env = getenv("LAB_DET");
+    const bool det = det_env == nullptr || atoi(det_env) != 0;
+    void* det_ws = nullptr;
+    if (det) {
+        CK(hipMalloc(&det_ws, (size_t)2048 << 20));
+        VB(vb_set_deterministic(1, det_ws, (int64_t)2048 << 20));
+    }
+    printf("---- vb_wgrad_bf16 (%s)\n", det ? "deterministic: partials + ordered reduce launch" : "fp32 atomics");
     for (const Wg& s : wg) {
         vb_wgrad_bf16_args g{};
         g.dY = dR; g.ldy = (int64_t)s.nseg * s.seg_n; g.X = dA; g.ldx = s.K; g.M = s.M; g.K = s.K; g.nseg = s.nseg; g.seg_n = s.seg_n; g.ldw = s.K;
