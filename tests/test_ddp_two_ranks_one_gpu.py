@@ -49,8 +49,8 @@ def _worker(rank, world, port, cfgname, delay, algorithm, q):
         from vilbert.optim import AdamW
         from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
         V._drop_p = lambda m: 0.0
-        V.set_two_streams(os.environ.get("DBG_TWO", "1") == "1")
-        AO.set_wgrad_stream(os.environ.get("DBG_WS", "1") == "1")
+        V.set_two_streams(True)
+        AO.set_wgrad_stream(True)
         dev = "cuda:0"
         cfg = synth.load_config(cfgname)
         n_tok, n_reg = (20, 37) if "2layer" in cfgname else (36, 37)
@@ -103,9 +103,6 @@ def _worker(rank, world, port, cfgname, delay, algorithm, q):
                 for n, g in want.items():
                     err = (g - grads[s][n]).abs().max().item()
                     bound = 1e-4 * g.abs().max().item() + 1e-6 * gmax
-                    if os.environ.get("DBG_ALL") and err > bound:
-                        print("BAD step %d %s: %.3e > %.3e" % (s, n, err, bound), flush=True)
-                        continue
                     assert err <= bound, "step %d %s: %.3e > %.3e" % (s, n, err, bound)
                     worst["grad"] = max(worst["grad"], err / bound)
                 ropt.step()
@@ -157,3 +154,96 @@ def test_two_ranks_share_one_gpu(cfgname, delay, algorithm):
             pytest.skip("this gloo build has no reduce_scatter / all_gather for device tensors (RCCL has; the CPU-tensor "
                         "path is covered by tests/test_distributed_cpu.py)")
         assert status == "ok", "rank %d:\n%s" % (rank, info)
+
+
+def _worker_bf16(rank, world, port, cfgname, q):
+    """The bf16 TRAINING step under the wrapper's defaults of that mode (round-5 review: bf16 exchange buckets + the direct
+    reduce-scatter / all-gather pair): gradients of two optimizer steps against one process over both halves, same mode."""
+    try:
+        for p in (os.path.join(ROOT, "vilbert-multi-task_amd"), ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import vilbert.vilbert as V
+        from apex.parallel import DistributedDataParallel as DDP
+        from oracle import synth
+        from vilbert import _native
+        from vilbert.optim import AdamW
+        from vilbert.vilbert import BertConfig, BertForMultiModalPreTraining
+        V._drop_p = lambda m: 0.0
+        _native.set_gemm_mode("bf16")
+        dev = "cuda:0"
+        cfg = synth.load_config(cfgname)
+        sd0 = synth.make_state_dict(cfg, "pretraining", seed=21)
+        x = synth.make_inputs(cfg, world * PER_RANK, 36, 37, seed=21, with_labels=True)
+        full = [x[n] for n in NAMES]
+        mine = [t[rank * PER_RANK:(rank + 1) * PER_RANK].to(dev) for t in full]
+
+        def build():
+            m = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
+            m.load_state_dict(sd0)
+            return m.to(dev).train()
+        net = build()
+        ddp = DDP(net, message_size=8 * 1024 * 1024)
+        assert ddp.algorithm == "direct" and ddp.bucket_dtype is torch.bfloat16, (ddp.algorithm, ddp.bucket_dtype)
+        opt = AdamW(net.parameters(), lr=LR, weight_decay=0.01)
+        grads = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            _loss(ddp(*mine)).backward()
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+            opt.step()
+        chk = torch.stack([p.detach().double().sum() for p in net.parameters()]).cpu()
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk)
+        assert torch.equal(both[0], both[1]), "ranks diverged"
+        info = {}
+        if rank == 0:
+            ref = build()
+            ropt = AdamW(ref.parameters(), lr=LR, weight_decay=0.01)
+            halves = [[t[r * PER_RANK:(r + 1) * PER_RANK].to(dev) for t in full] for r in range(world)]
+            for s in range(2):
+                ropt.zero_grad(set_to_none=True)
+                (sum(_loss(ref(*h)) for h in halves) / world).backward()
+                torch.cuda.synchronize()
+                want = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+                assert want.keys() == grads[s].keys()
+                rel = sorted(float((grads[s][n].double() - g.double()).norm() / g.double().norm().clamp_min(1e-12))
+                             for n, g in want.items() if not (".key" in n and n.endswith("bias")))
+                info["step%d" % s] = (rel[len(rel) // 2], rel[-1])
+                # bf16 buckets round every averaged gradient to 8 bits of mantissa (2^-9 relative per element). The second step
+                # also carries the weights' divergence of the first: AdamW's first update is lr * sign(g) wherever v is fresh, so
+                # a gradient element whose sign the bucket rounding flipped moves its weight by 2 lr - a sanity bound only there
+                bound = (6e-3, 5e-2) if s == 0 else (5e-2, 2.0)
+                assert rel[len(rel) // 2] <= bound[0] and rel[-1] <= bound[1], "step %d: median %.2e worst %.2e" % (
+                    s, rel[len(rel) // 2], rel[-1])
+                ropt.step()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", info))
+    except Exception:   # noqa: BLE001
+        q.put((rank, "fail", traceback.format_exc()))
+
+
+def test_two_ranks_share_one_gpu_bf16_step_with_its_default_exchange():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, 2, port, "bert_base_2layer_2conect.json", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, status, info in sorted(res):
+        if status != "ok" and "gloo" in str(info).lower() and ("support" in str(info).lower() or "bfloat16" in str(info).lower()):
+            pytest.skip("this gloo build cannot exchange bfloat16 device tensors (RCCL can; bf16 buckets on CPU tensors: "
+                        "tests/test_distributed_cpu.py)")
+        assert status == "ok", "rank %d:\n%s" % (rank, info)
+        if rank == 0:
+            print("bf16 step under DDP (bf16 buckets, direct): gradient relative L2 vs one process, (median, worst) per step:", info)

@@ -63,9 +63,16 @@ def test_two_hundred_steps_with_and_without_dropout_against_the_oracle():
     dev_batches = [helpers.to_device(b, DEV) for b in batches]
 
     def run(dropout_on):
+        import itertools
+        import vilbert.autograd_ops as AO
         orig = V._drop_p
         if not dropout_on:
             V._drop_p = lambda m: 0.0
+        # the dropout masks are a function of (torch's seed, a per-process call counter): restart both, so that the statistical
+        # bounds below see the same masks whatever ran before this test (round 6: the bounds tripped once inside the full suite
+        # after new tests had moved the counter, and passed alone)
+        torch.manual_seed(20260930)
+        AO._seed_counter = itertools.count(1)
         try:
             net = BertForMultiModalPreTraining(BertConfig.from_dict(cfg))
             net.load_state_dict(sd)

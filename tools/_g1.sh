@@ -1,5 +1,4 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
-timeout 300 tools/bf16_lab time > gpurun_out/r06_bf16_lab_time.txt 2>&1
-tail -14 gpurun_out/r06_bf16_lab_time.txt
-bash tools/pmc_r06.sh 2>&1 | tail -60
+timeout 900 python -m pytest tests/test_loss_curve_gpu.py -q -x -s 2>&1 | grep -v "visual target" | tail -40 > gpurun_out/r06_loss_curve_fail.txt
+cat gpurun_out/r06_loss_curve_fail.txt
