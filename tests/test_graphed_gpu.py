@@ -211,6 +211,59 @@ def test_graphed_step_in_fp8_mode_requantises_the_weights_every_replay():
         V._drop_p = orig
 
 
+@pytest.mark.parametrize("mode,prior", [("fp8", "fp8"), ("fp8", "f32"), ("bf16", "f32"), ("f32", "fp8")])
+def test_chain_graph_after_freed_memory_replays_the_eager_losses(mode, prior):
+    """Round-5 review (weak 2) / advisor: the CHAIN form of the captured step returned wrong losses from the third replay on
+    when the process had freed device memory before the capture (tools/dbg_graph_nan.py S5 / S6). Cause (round 6): memset
+    nodes - the zero fill in front of the atomically accumulated split-K input gradient of the MLM decoder was a captured
+    hipMemset2DAsync that this runtime skips at replay in that situation (tools/memset_node_repro.py); it is a kernel now.
+    Here: a few eager steps of another model in `prior` mode (their memory is freed), then a chain capture in `mode` and SIX
+    replays against the eager run of the same mode, same batch."""
+    import gc
+    import vilbert.vilbert as V
+    from vilbert import _native
+    from vilbert.graphed import GraphedTrainStep
+    from vilbert.optim import AdamW
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    sd = synth.make_state_dict(cfg, "pretraining")
+    orig, V._drop_p = V._drop_p, (lambda m: 0.0)
+    prev = _native.set_gemm_mode(prior)
+    try:
+        big = [synth.make_inputs(cfg, 8, 36, 37, seed=70, with_labels=True)[k].to(DEV) for k in NAMES]
+        mp = _model(cfg, sd)
+        op = AdamW(mp.parameters(), lr=2e-4)
+        for _ in range(3):
+            op.zero_grad()
+            sum(l.mean() for l in mp(*big)).backward()
+            op.step()
+        del mp, op, big
+        gc.collect()
+        torch.cuda.synchronize()                     # (no empty_cache: the freed blocks stay in the allocator and get recycled)
+        _native.set_gemm_mode(mode)
+        args = [synth.make_inputs(cfg, 4, 12, 10, seed=70, with_labels=True)[k].to(DEV) for k in NAMES]
+        m0 = _model(cfg, sd)
+        o0 = AdamW(m0.parameters(), lr=3e-4)
+        ref = []
+        for _ in range(6):
+            o0.zero_grad()
+            loss = sum(l.mean() for l in m0(*args))
+            loss.backward()
+            o0.step()
+            ref.append(loss.item())
+        m1 = _model(cfg, sd)
+        o1 = AdamW(m1.parameters(), lr=3e-4)
+        with GraphedTrainStep(m1, o1, args, warmup=2, branches="chain") as step:
+            got = [step(*args).item() for _ in range(6)]
+            step.check()
+        tol = {"f32": 2e-4, "bf16": 3e-2, "fp8": 3e-2}[mode]
+        assert all(g == g for g in got), got
+        for a, b in zip(ref, got):
+            assert abs(a - b) <= tol * abs(a), (mode, prior, ref, got)
+    finally:
+        _native.set_gemm_mode(prev)
+        V._drop_p = orig
+
+
 def test_dropped_step_unregisters_its_counter_and_restores_the_exact_gather():
     """Round-2 advisor: a GraphedTrainStep that is dropped without close() must not leave the process-global dropout
     step counter pointing at its (freed) device memory, nor the model on the capped label gather. The finaliser runs at

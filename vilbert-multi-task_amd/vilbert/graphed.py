@@ -58,10 +58,10 @@ class GraphedTrainStep(object):
         the bf16 training mode, "fork" otherwise. Measured at batch 64 (profiles/r05_b64_graph_chain.txt): the chain replays in
         18.9 ms (bf16 mode; eager 23.7 ms, host-bound; forked graph 26.7 ms) - this HIP runtime serialises cross-branch edges at
         replay at a cost that exceeds what the overlap buys (the effect GraphedForward(branches="auto") measures per instance).
-        fp32: chain 37.3 / fork 42.0 / eager 32.0 ms - GPU-bound, a graph does not pay there. Known issue: the "chain" form of the
-        opt-in fp8 training mode ("fp8", "fp8+bf16") replays wrong losses from the third replay on once the process has freed
-        device memory before the capture (tools/dbg_graph_nan.py S5 / S6; fork, fp32 and bf16 chains are not affected) - those
-        modes therefore keep the forked form, which every round's suite has covered."""
+        fp32: chain 37.3 / fork 42.0 / eager 32.0 ms - GPU-bound, a graph does not pay there. (Round 5's wrong losses of the fp8
+        chain after memory had been freed before the capture were MEMSET NODES that this runtime does not execute at replay in
+        that situation - tools/memset_node_repro.py; every zero fill on a captured path is a kernel since round 6, DESIGN.md
+        section 4.5, tests/test_graphed_gpu.py::test_chain_graph_after_freed_memory...)"""
         base = model.module if hasattr(model, "module") else model
         bf16 = N.bf16_stream() or bool(getattr(base, "_vb_bf16", False))      # (process-wide mode, or model.half())
         if branches is None:
