@@ -1104,6 +1104,9 @@ def main():
                 "fwd_mxfp8_b512": pick(line, "fwd_mxfp8_b512", "value"),
                 "fwd_mxfp8_b512_gemm_frac": pick(line, "fwd_mxfp8_b512", "roofline", "frac"),
                 "fwd_mxfp8_b512_rank": pick(line, "fwd_mxfp8_b512", "rank_statistics"),
+                "train_bf16x6_b256": pick(line, "alt_gemm_modes", "bf16x6", "value"),
+                "train_bf16x6_note": "fp32 operands as 3 bf16 planes, 6 MFMA products, fp32 accumulate: passes the SAME 1e-4 parity "
+                                     "tests against the reference's goldens (tests/test_gemm_modes_gpu.py); opt-in, not the headline",
                 "train_bf16_b256": pick(line, "alt_gemm_modes", "bf16", "value"),
                 "train_bf16_gemm_frac": pick(line, "alt_gemm_modes", "bf16", "roofline", "frac"),
                 "train_bf16_b64": pick(line, "alt_gemm_modes", "bf16", "b64", "value"),

@@ -211,6 +211,42 @@ def claim(param):
     return view, mode, e[0], e[1]
 
 
+def claim_many(params):
+    """claim() for every parameter of a list, with the per-pass work (enter_pass, wait_for_fill) done once per arena instead of
+    once per parameter (round 6: a whole-layer backward node claims 16 - 22 slices at once; 509 claims per step were 1.4 ms of
+    the host's 15 ms at the per-GPU batch 64). Same results as [claim(p) for p in params]."""
+    out = []
+    ready = None                                       # the arena whose pass has been entered by this call
+    for param in params:
+        e = _BY_PTR.get(param.data_ptr())
+        arena = e[0]() if e is not None else None
+        if arena is None or arena.flat is None or arena.params[e[1]] is not param:
+            out.append(claim(param))                   # (unknown / stale entry: the careful path)
+            continue
+        i = e[1]
+        if arena is not ready:
+            if not arena.enter_pass():
+                out.append((None, None, None, None))
+                continue
+            arena.wait_for_fill()
+            ready = arena
+        if i in arena._written:
+            out.append((arena.views[i], "accum", arena, i))
+            continue
+        g = param.grad
+        if g is None:
+            if arena._accumulating:
+                arena.views[i].zero_()
+            arena._written.add(i)
+            out.append((arena.views[i], "fresh", arena, i))
+        elif g.data_ptr() == arena.views[i].data_ptr():
+            arena._written.add(i)
+            out.append((arena.views[i], "accum", arena, i))
+        else:
+            out.append((None, None, None, None))
+    return out
+
+
 def result(mode, arena, index, fallback):
     """What a backward node returns for a parameter whose gradient it wrote through claim()."""
     if mode == "fresh":
