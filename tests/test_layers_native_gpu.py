@@ -162,3 +162,59 @@ def test_layer_launcher_steps_aside_for_what_it_does_not_serve():
         assert layers.native_calls() == c0
     finally:
         _native.set_gemm_mode(prev)
+
+
+def test_replaced_submodules_parameters_and_moved_storage_are_noticed_by_the_plans():
+    """The whole-layer nodes keep per-module plans (parameter lists, static argument structs). They must follow what a user
+    does to the model between two calls: a sub-module replaced (adapter-style), a Parameter object replaced, the model moved
+    to new storage (.cpu().to(dev)) - each time the launcher's outputs equal the per-op path's on the CURRENT weights (and
+    differ from the outputs before the edit)."""
+    from vilbert import _native, layers
+    from vilbert.vilbert import BertConfig, VILBertForVLTasks
+    cfg = synth.load_config("bert_base_2layer_2conect.json")
+    sd = synth.make_state_dict(cfg, "vltasks")
+    x = synth.make_inputs(cfg, 3, 12, 9, seed=4)
+    args = helpers.to_device((x["input_ids"], x["image_feat"], x["image_loc"], x["token_type_ids"], x["attention_mask"],
+                              x["image_attention_mask"], x["co_attention_mask"]), DEV)
+    m = VILBertForVLTasks(BertConfig.from_dict(cfg), num_labels=1)
+    m.load_state_dict(sd)
+    m = m.eval().to(DEV)
+    prev_mode = _native.set_gemm_mode("f32")
+
+    def both():
+        with torch.no_grad():
+            prev = layers.set_native(True)
+            c0 = layers.native_calls()
+            got = [o.clone() for o in m(*args)[:9]]
+            assert layers.native_calls() > c0
+            layers.set_native(False)
+            want = m(*args)[:9]
+            layers.set_native(prev)
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+        return got
+    try:
+        base = both()
+        g = torch.Generator().manual_seed(3)
+        enc = m.bert.encoder
+        old = enc.layer[3].attention.self.key
+        new = torch.nn.Linear(old.in_features, old.out_features)
+        new.weight.data.copy_(torch.randn(new.weight.shape, generator=g) * 0.05)
+        enc.layer[3].attention.self.key = new.to(DEV)                                  # a replaced sub-module
+        a = both()
+        assert not torch.equal(a[0], base[0])
+        bi = enc.c_layer[1].biattention
+        bi.value2.bias = torch.nn.Parameter((torch.randn(bi.value2.bias.shape, generator=g) * 0.5).to(DEV))   # a replaced Parameter
+        b = both()
+        assert not torch.equal(b[0], a[0])
+        with torch.no_grad():
+            enc.v_layer[0].output.dense.weight.mul_(1.5)                               # an in-place edit (same object, same storage)
+        c = both()
+        assert not torch.equal(c[0], b[0])
+        m.cpu()
+        m.to(DEV)                                                                      # same objects, new addresses
+        d = both()
+        for u, v in zip(c, d):
+            assert torch.equal(u, v)
+    finally:
+        _native.set_gemm_mode(prev_mode)

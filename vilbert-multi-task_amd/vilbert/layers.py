@@ -15,7 +15,8 @@ weight-gradient side stream (autograd_ops.py rules).
 
 Plans: what does not change from call to call - the module's parameters in launcher order, its eligibility, the layout of the
 two buffers, and the argument struct with every STATIC field filled (dimensions, fp32 weight / bias / LayerNorm pointers) - is
-kept per (module, dtype, shape, mode) and revalidated per call by the parameters' identities and addresses; a call copies the
+kept per (module, dtype, shape, mode) and revalidated per call: the module tree below the layer and every parameter OBJECT by
+identity (plain dict lookups), every parameter address per plan; a call copies the
 struct and fills the per-call pointers, probabilities and seeds. (The bf16 weight shadows are still asked for on every call:
 that is where a stale shadow gets refreshed.)
 
@@ -579,6 +580,41 @@ class _NoCtx(object):
 
 _REFUSED = object()      # cached verdict: this (module, key) goes op by op
 
+_SELF_PATHS = ["attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense",
+               "attention.output.LayerNorm", "intermediate.dense", "output.dense", "output.LayerNorm"]
+_CONN_PATHS = ["biattention.query1", "biattention.key1", "biattention.value1", "biattention.query2", "biattention.key2",
+               "biattention.value2", "biOutput.dense1", "biOutput.LayerNorm1", "v_intermediate.dense", "v_output.dense",
+               "v_output.LayerNorm", "biOutput.dense2", "biOutput.LayerNorm2", "t_intermediate.dense", "t_output.dense",
+               "t_output.LayerNorm"]
+
+
+def _wiring(layer, paths):
+    """The (parent, child name, child) edges from `layer` down to the leaf modules of `paths` and their (leaf, "weight" / "bias",
+    parameter) slots, as found NOW: _wired() compares them with plain dict lookups on every call - a replaced sub-module
+    (adapter wrappers), a replaced or re-parametrised Parameter object sends the module back through the full judgement."""
+    edges, slots, seen = [], [], set()
+    for path in paths:
+        m = layer
+        for name in path.split("."):
+            child = m._modules[name]
+            if (id(m), name) not in seen:
+                seen.add((id(m), name))
+                edges.append((m, name, child))
+            m = child
+        for pname in ("weight", "bias"):
+            slots.append((m, pname, m._parameters.get(pname)))
+    return edges, slots
+
+
+def _wired(wiring):
+    for m, name, child in wiring[0]:
+        if m._modules.get(name) is not child:
+            return False
+    for m, pname, p in wiring[1]:
+        if m._parameters.get(pname) is not p:
+            return False
+    return True
+
 
 _PLANS = weakref.WeakKeyDictionary()      # module -> its plans (outside the module: deepcopy / pickle of a model never see them)
 
@@ -610,18 +646,19 @@ def self_layer(layer, x, mask, drop_attn, drop_o, drop_f):
     # one entry per (dtype, shape): (parameters in launcher order, {training: plan}) or the refusal
     key = (b16, B, S)
     ent = cache.get(key)
-    if ent is not None:
-        # the modules still hold the parameter objects the verdict was made for (checked on two of them; their addresses are
-        # checked per plan)
-        if att.query.weight is not ent[0][0] or layer.output.dense.weight is not ent[0][12]:
-            ent = None
+    if ent is not None and not _wired(ent[2]):
+        ent = None       # (the module tree / its parameter objects are not the ones the verdict was made for; addresses: per plan)
     if ent is None:
-        params = _self_params(layer)
+        try:
+            wiring = _wiring(layer, _SELF_PATHS)
+            params = _self_params(layer)
+        except (KeyError, AttributeError):
+            return None                                   # (not the reference's module tree: op by op)
         ok = not any(p is None for p in params) and S <= ops.MAX_KEYS and att.attention_head_size in (32, 64, 128) \
             and att.all_head_size == H and _linear_ok(params[0:6:2], params[1:6:2], b16) \
             and _block_ok(params[6:], b16, layer.intermediate.intermediate_act_fn)
-        ent = cache[key] = (params, {} if ok else _REFUSED)
-    params, plans = ent
+        ent = cache[key] = (params, {} if ok else _REFUSED, wiring)
+    params, plans, _w = ent
     if plans is _REFUSED:
         return None
     state = _grad_state((x,), params)
@@ -671,18 +708,21 @@ def connection_layer(layer, x1, mask1, x2, mask2, drops, concurrent):
     cache = _cache_of(layer)
     key = (b16, B, n1, n2)
     ent = cache.get(key)
-    if ent is not None:
-        if bi.query1.weight is not ent[0][0] or layer.t_output.dense.weight is not ent[2][6]:
-            ent = None
+    if ent is not None and not _wired(ent[5]):
+        ent = None
     if ent is None:
-        qkv, blk1, blk2 = _conn_params(layer)
+        try:
+            wiring = _wiring(layer, _CONN_PATHS)
+            qkv, blk1, blk2 = _conn_params(layer)
+        except (KeyError, AttributeError):
+            return None
         ok = not any(p is None for p in qkv + blk1 + blk2) and max(n1, n2) <= ops.MAX_KEYS \
             and bi.attention_head_size in (32, 64, 128) \
             and _linear_ok(qkv[0:6:2], qkv[1:6:2], b16) and _linear_ok(qkv[6::2], qkv[7::2], b16) \
             and _block_ok(blk1, b16, layer.v_intermediate.intermediate_act_fn) \
             and _block_ok(blk2, b16, layer.t_intermediate.intermediate_act_fn)
-        ent = cache[key] = (qkv, blk1, blk2, qkv + blk1 + blk2, {} if ok else _REFUSED)
-    qkv, blk1, blk2, allp, plans = ent
+        ent = cache[key] = (qkv, blk1, blk2, qkv + blk1 + blk2, {} if ok else _REFUSED, wiring)
+    qkv, blk1, blk2, allp, plans, _w = ent
     if plans is _REFUSED:
         return None
     state = _grad_state((x1, x2), allp)
