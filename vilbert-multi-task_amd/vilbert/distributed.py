@@ -38,13 +38,18 @@ Design for MI355X (8 GPUs, 7 xGMI links per GPU, 288 GB HBM each):
     the bytes, and widened back into the fp32 arena range; master gradients, optimizer state and weights stay fp32.
 Works with any ``torch.distributed`` backend (``nccl`` = RCCL on ROCm; ``gloo`` for the CPU tests).
 """
+import contextlib
 import math
+import os
 
 import torch
 import torch.distributed as dist
 from torch import nn
 
+from . import _native as _N
 from .arena import GradArena
+
+_LAUNCH_MODE = os.environ.get("VB_DDP_LAUNCH", "cur")      # "ls": bucket exchanges issued from a launch stream (experiment, see _launch)
 
 
 class _Bucket(object):
@@ -62,6 +67,7 @@ class _Bucket(object):
 
     def reset(self):
         self.ready = set()
+        self.hits = 0            # how many of `expected` are in `ready` (ready == expected <=> hits == len(expected) == len(ready))
         self.streams = {}        # raw stream handle -> stream on which some gradient of this bucket was produced
         self.work = None
         self.launched = False
@@ -141,6 +147,10 @@ class DistributedDataParallel(nn.Module):
                 self._where[id(p)] = (b, i)
                 p.register_post_accumulate_grad_hook(self._hook)
         self.arena.add_listener(self)
+        self._view_ptrs = [v.data_ptr() for v in self.arena.views]
+        self._cuda = self.arena.flat.is_cuda
+        self._dev_index = self.arena.flat.device.index if self._cuda else None
+        self._launch_stream = None  # the stream bucket exchanges are issued from (see _launch)
         self._pass = None           # autograd graph-task id of the pass being tracked
         self._finalized = True
 
@@ -159,11 +169,14 @@ class DistributedDataParallel(nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def _hook(self, param):
+        # (538 calls per backward pass: kept lean - cached slice addresses, raw stream handles, a counter instead of a set
+        # comparison; in the bf16 mode, whose step the host can barely keep ahead of, the hooks + the finalize loop were
+        # ~4.8 ms of a 26 ms step, tools/ddp_overhead.py)
         self._enter_pass()
         b, i = self._where[id(param)]
-        view = self.arena.views[i]
         g = param.grad
-        if g is not None and g.data_ptr() != view.data_ptr():
+        if g is not None and g.data_ptr() != self._view_ptrs[i]:
+            view = self.arena.views[i]
             # produced by a foreign autograd node: move it into the bucket (the native kernels write in place).
             # The arena's pass must have begun first: a foreign gradient can arrive before the first native claim()
             # (a torch head on top of the native body), and the fill of that claim would otherwise wipe the copy.
@@ -174,49 +187,74 @@ class DistributedDataParallel(nn.Module):
                 "DistributedDataParallel: parameter of shape %s received its gradient after its bucket had been "
                 "all-reduced - the set of used parameters changed between steps; construct with "
                 "delay_allreduce=True (the reference's multi-task mode, train_tasks.py:497)" % (tuple(param.shape),))
-        b.ready.add(i)
-        if g is not None and g.is_cuda:
+        if i not in b.ready:
+            b.ready.add(i)
+            if b.expected is not None and i in b.expected:
+                b.hits += 1
+        if self._cuda:
             # the model runs its text / image streams on two HIP streams, so gradients of one bucket
             # are produced on different streams: remember which (no event per gradient - a stream is
             # in-order, so waiting for the stream at launch time covers every gradient enqueued on it)
-            st = torch.cuda.current_stream(g.device)
-            b.streams.setdefault(st.cuda_stream, st)
-        if not self.delay_allreduce and b.expected is not None and b.ready == b.expected:
+            handle = _N.raw_stream(self._dev_index)
+            if handle not in b.streams:
+                b.streams[handle] = torch.cuda.current_stream(self.arena.flat.device)
+        if not self.delay_allreduce and b.expected is not None and b.hits == len(b.expected) and len(b.ready) == b.hits:
             self._launch(b)
 
     def _launch(self, b):
         """Start the in-place all-reduce of the bucket's arena range."""
         from . import autograd_ops as _A
-        _A.join_wgrad_streams()      # weight gradients are written on side streams of the backward streams
-        if b.streams:
-            cur = torch.cuda.current_stream()
+        # What the exchange has to wait for - the other encoder stream, the weight-gradient side streams - is waited for by
+        # the CURRENT backward stream; the process group's stream orders itself behind that stream at the call.
+        # (Round 6 experiment, VB_DDP_LAUNCH=ls: issue the waits and the collective from a launch stream of the wrapper
+        # instead, so that the backward stream never waits for the side streams. Measured at world size 1 with the collectives
+        # stubbed out (tools/ddp_overhead2.py, bf16 step 26.4 ms): waits on the current stream + 1.6 ms, launch stream
+        # + 10.9 ms - a third stream that waits on events of the compute stream 14 times per pass costs far more than the
+        # waits it takes off that stream; profiles/r06_ddp_overhead_launch_modes.txt. Not the default.)
+        cuda = b.flat.is_cuda
+        ctx = contextlib.nullcontext()
+        if cuda and _LAUNCH_MODE == "ls":
+            cur = torch.cuda.current_stream(b.flat.device)
+            ls = self._launch_stream
+            if ls is None or ls.device != b.flat.device:
+                ls = self._launch_stream = torch.cuda.Stream(device=b.flat.device)
+            ls.wait_stream(cur)
+            _A.join_wgrad_streams(into=ls)
+            for handle, st in b.streams.items():
+                if handle != cur.cuda_stream:
+                    ls.wait_stream(st)
+            ctx = torch.cuda.stream(ls)
+        elif cuda:
+            cur = torch.cuda.current_stream(b.flat.device)
+            _A.join_wgrad_streams()      # weight gradients are written on side streams of the backward streams
             for handle, st in b.streams.items():
                 if handle != cur.cuda_stream:
                     cur.wait_stream(st)
-        if self.trace is not None and b.flat.is_cuda:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            self.trace.append((b.index, b.flat.numel() * b.flat.element_size(), ev))
-        op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
-        buf = b.flat
-        if self.bucket_dtype is not None:
-            if b.stage is None:
-                b.stage = torch.empty(b.flat.numel(), dtype=self.bucket_dtype, device=b.flat.device)
-            b.stage.copy_(b.flat)                 # round to the exchange precision (one elementwise pass)
-            buf = b.stage
-        if self.algorithm == "ring" or (self.world_size == 1 and not self.direct_at_world_size_one):
-            b.work = [dist.all_reduce(buf, op=op, group=self.group, async_op=True)]
-        else:
-            # two-phase exchange, both phases in place: this rank's shard is a view of the range
-            n = buf.numel() // self.world_size
-            r = dist.get_rank(self.group)
-            shard = buf[r * n:(r + 1) * n]
-            rs = dist.reduce_scatter_tensor(shard, buf, op=op, group=self.group, async_op=True)
-            if not self._native_avg:
-                rs.wait()                         # gloo runs asynchronous work on a thread pool: order the phases by hand
-            # (RCCL enqueues both on the process group's stream, in issue order)
-            ag = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
-            b.work = [rs, ag]
+        with ctx:
+            if self.trace is not None and cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.trace.append((b.index, b.flat.numel() * b.flat.element_size(), ev))
+            op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
+            buf = b.flat
+            if self.bucket_dtype is not None:
+                if b.stage is None:
+                    b.stage = torch.empty(b.flat.numel(), dtype=self.bucket_dtype, device=b.flat.device)
+                b.stage.copy_(b.flat)                 # round to the exchange precision (one elementwise pass)
+                buf = b.stage
+            if self.algorithm == "ring" or (self.world_size == 1 and not self.direct_at_world_size_one):
+                b.work = [dist.all_reduce(buf, op=op, group=self.group, async_op=True)]
+            else:
+                # two-phase exchange, both phases in place: this rank's shard is a view of the range
+                n = buf.numel() // self.world_size
+                r = dist.get_rank(self.group)
+                shard = buf[r * n:(r + 1) * n]
+                rs = dist.reduce_scatter_tensor(shard, buf, op=op, group=self.group, async_op=True)
+                if not self._native_avg:
+                    rs.wait()                         # gloo runs asynchronous work on a thread pool: order the phases by hand
+                # (RCCL enqueues both on the process group's stream, in issue order)
+                ag = dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
+                b.work = [rs, ag]
         b.launched = True
 
     def arena_backward_done(self):
@@ -239,8 +277,9 @@ class DistributedDataParallel(nn.Module):
                 b.flat.copy_(b.stage)             # widen the exchanged values back into the fp32 arena range
             if not self._native_avg:
                 b.flat.div_(self.world_size)
+            params, ptrs = self.arena.params, self._view_ptrs
             for i in b.ready:
-                p = self.arena.params[i]
-                if p.grad is None or p.grad.data_ptr() != self.arena.views[i].data_ptr():
-                    p.grad = self.arena.alias(i)
+                g = params[i].grad
+                if g is None or g.data_ptr() != ptrs[i]:
+                    params[i].grad = self.arena.alias(i)
             b.expected = set(b.ready)    # learnt / refreshed for the next pass
