@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
-timeout 1800 python -m pytest tests/test_ddp_two_ranks_one_gpu.py tests/test_arena_gpu.py -q 2>&1 | grep -v "visual target" | grep -E "passed|failed|Error" | tail -3
-KINDS=plain,normal,delay VB_GEMM_MODE=bf16 timeout 900 python tools/ddp_overhead2.py 2>&1 | grep -E "wall"
+DDP_MIB=1024 VB_GEMM_MODE=bf16 timeout 900 python tools/ddp_overhead.py 2>&1 | grep -E "plain step|stand-alone" > gpurun_out/r06_ddp_one_rank_avg.txt
+cat gpurun_out/r06_ddp_one_rank_avg.txt

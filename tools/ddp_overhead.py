@@ -31,7 +31,10 @@ inp = tuple(x[n].to(dev) for n in names)
 
 def run(wrap, stub):
     model = bench.build_model(cfg, "pretraining", dev).train()
-    net = DDP(model) if wrap else model
+    mib = int(os.environ.get("DDP_MIB", "64"))
+    net = DDP(model, message_size=mib * (1 << 20) // 4, delay_allreduce=os.environ.get("DDP_DELAY") == "1") if wrap else model
+    if wrap:
+        print("buckets:", len(net._buckets), "of", mib, "MiB; delay_allreduce:", net.delay_allreduce)
     opt = AdamW(net.parameters(), lr=1e-4)
     real = dist.all_reduce
 
@@ -72,6 +75,20 @@ for _ in range(5):
     dist.all_reduce(buf)
 torch.cuda.synchronize()
 ar = 1e3 * (time.perf_counter() - t0) / 5
+def _time_ar(t, op):
+    for _ in range(2):
+        dist.all_reduce(t, op=op)
+    torch.cuda.synchronize()
+    t0_ = time.perf_counter()
+    for _ in range(5):
+        dist.all_reduce(t, op=op)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0_) / 5
+
+
+print("stand-alone one-rank all_reduce: fp32 1 GB SUM %.2f ms, AVG %.2f ms; bf16 0.5 GB SUM %.2f ms, AVG %.2f ms" % (
+    _time_ar(buf, dist.ReduceOp.SUM), _time_ar(buf, dist.ReduceOp.AVG), _time_ar(buf.bfloat16(), dist.ReduceOp.SUM),
+    _time_ar(buf.bfloat16(), dist.ReduceOp.AVG)))
 print("plain step %.2f ms | DDP hooks + bookkeeping only %.2f ms (+%.1f %%) | DDP with one-rank RCCL all-reduce %.2f ms "
       "(+%.1f %%) | stand-alone one-rank all-reduce of 1 GB: %.2f ms" % (plain, hooks, 100 * (hooks / plain - 1), full,
                                                                           100 * (full / plain - 1), ar))
