@@ -72,6 +72,8 @@ def test_struct_layouts_match_the_header(native):
                            ("vb_linear_bwd_weight_args", native.LinearBwdWeightArgs),
                            ("vb_linear_fp8_args", native.LinearFp8Args), ("vb_linear_mx_args", native.LinearMxArgs), ("vb_attention_mx_args", native.AttentionMxArgs),
                            ("vb_adamw_tensor", native.AdamWTensor), ("vb_concap_batch", native.ConcapBatch),
+                           ("vb_linear_bf16_args", native.LinearBf16Args), ("vb_wgrad_bf16_args", native.WgradBf16Args),
+                           ("vb_attention_bf16_grads", native.AttentionGrads),
                            ("vb_layer_linear", native.LayerLinear), ("vb_layer_norm", native.LayerNormP),
                            ("vb_ffn_block", native.FfnBlock), ("vb_attn_block", native.AttnBlock),
                            ("vb_layer_args", native.LayerArgs)):
