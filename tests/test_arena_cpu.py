@@ -211,3 +211,59 @@ def test_registry_does_not_keep_arenas_alive():
     del ar
     gc.collect()
     assert ref() is None and A.lookup(w) is None
+
+
+class ToyBlock(Function):
+    """Two linears as ONE node that claims all its targets at once (claim_many), like the whole-layer nodes of layers.py."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3):
+        ctx.save_for_backward(x, w1, w2, w3)
+        return (x @ w1.t()) @ w2.t() + 0.0 * w3.sum()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, w3 = ctx.saved_tensors
+        h = x @ w1.t()
+        claims = A.claim_many([w1, w2, w3])
+        grads = [(dy @ w2).t() @ x, dy.t() @ h, torch.zeros_like(w3)]
+        out = []
+        for (view, mode, ar, idx), g in zip(claims, grads):
+            if view is None:
+                out.append(g)
+            else:
+                view.add_(g)
+                out.append(A.result(mode, ar, idx, None))
+        return ((dy @ w2) @ w1,) + tuple(out)
+
+
+def test_claim_many_is_claim_for_every_parameter():
+    """arena.claim_many (round 6: one pass-entry per arena for the 16 - 22 targets of a whole-layer backward node) must behave
+    exactly like claim() per parameter: fresh / accumulating / tied / foreign gradients, a parameter outside the arena, and
+    outside a backward pass."""
+    torch.manual_seed(1)
+    w1, w2, w3 = nn.Parameter(torch.randn(4, 3)), nn.Parameter(torch.randn(2, 4)), nn.Parameter(torch.randn(5))
+    ar = A.GradArena([w1, w2])                         # w3 is NOT managed
+    x = torch.randn(6, 3)
+    assert A.claim_many([w1, w2, w3]) == [(None, None, None, None)] * 3       # not inside a backward pass
+
+    def loss():
+        return (ToyBlock.apply(x, w1, w2, w3) ** 2).sum() + (ToyLinear.apply(x, w1) ** 2).sum()     # w1: a second, per-op writer
+
+    def reference():
+        a, b = w1.detach().clone().requires_grad_(True), w2.detach().clone().requires_grad_(True)
+        ((((x @ a.t()) @ b.t()) ** 2).sum() + ((x @ a.t()) ** 2).sum()).backward()
+        return a.grad, b.grad
+    r1, r2 = reference()
+    loss().backward()
+    i1, i2 = A.lookup(w1)[1], A.lookup(w2)[1]
+    assert w1.grad.data_ptr() == ar.views[i1].data_ptr() and w2.grad.data_ptr() == ar.views[i2].data_ptr()
+    assert torch.allclose(w1.grad, r1, atol=1e-5) and torch.allclose(w2.grad, r2, atol=1e-5)
+    assert w3.grad is not None and float(w3.grad.abs().max()) == 0.0 and A.lookup(w3) is None
+    loss().backward()                                   # accumulation into owned slices
+    assert torch.allclose(w1.grad, 2 * r1, atol=1e-4) and torch.allclose(w2.grad, 2 * r2, atol=1e-4)
+    w1.grad, w2.grad, w3.grad = None, torch.ones(2, 4), None          # one fresh, one foreign
+    loss().backward()
+    assert torch.allclose(w1.grad, r1, atol=1e-5) and w1.grad.data_ptr() == ar.views[i1].data_ptr()
+    assert torch.allclose(w2.grad, 1 + r2, atol=1e-5) and w2.grad.data_ptr() != ar.views[i2].data_ptr()
+    ar.release()
