@@ -226,15 +226,32 @@ int fork_to(void* main_st, void* side_st) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-// dW of `L` from (dY, X), which the launch stream has just produced: on the side stream (behind an event) when there is one
+// The weight gradients of one vb_layer_bwd call are COLLECTED while the launch stream runs the call's critical path
+// (LayerNorm / input-gradient / attention backward) and launched together at its end: behind ONE event on the side stream
+// when there is one. A cross-stream rendezvous costs the PRODUCER stream 13 - 19 us on this runtime whatever the event
+// flags (tools/event_cost.hip, profiles/r06_event_cost.txt: the marker drains the stream's pipeline), so one fork per weight
+// gradient - 121 per training step - was ~1.9 ms of bubbles on the backward stream; one per call is 36. Nothing a deferred
+// launch reads is overwritten later in the same call (every gradient buffer of a call is written once), and the kernels,
+// their inputs and therefore the results are the same.
+struct WgradJob { long M; const vb_layer_linear* L; const void* dY; const void* X; };
+struct WgradQueue {
+    WgradJob job[8];
+    int n = 0;
+    void push(long M, const vb_layer_linear& L, const void* dY, const void* X) {
+        if (wants_wgrad(L) && n < 8) job[n++] = WgradJob{M, &L, dY, X};
+    }
+};
+
 template <bool B16>
-int wgrad_side(void* st, void* side, long M, const vb_layer_linear& L, const void* dY, const void* X) {
-    if (!wants_wgrad(L)) return 0;
+int wgrad_flush(void* st, void* side, const WgradQueue& q) {
+    if (q.n == 0) return 0;
+    void* target = st;
     if (side != nullptr && side != st) {
         VB_TRY(fork_to(st, side));
-        return wgrad<B16>(side, M, L, dY, X);
+        target = side;
     }
-    return wgrad<B16>(st, M, L, dY, X);
+    for (int i = 0; i < q.n; ++i) VB_TRY(wgrad<B16>(target, q.job[i].M, *q.job[i].L, q.job[i].dY, q.job[i].X));
+    return 0;
 }
 
 AttnCall self_call(const vb_attn_block& b, bool b16) {
@@ -292,27 +309,28 @@ int ffn_block_fwd(void* st, const vb_ffn_block& f, bool training) {
 }
 
 template <bool B16>
-int ffn_block_bwd(void* st, void* side, const vb_ffn_block& f) {
+int ffn_block_bwd(void* st, WgradQueue& wq, const vb_ffn_block& f) {
     if (f.M == 0) return 0;
     // y = LN(sum2)
     VB_TRY(ln_bwd<B16>(st, f.M, f.H, f.dy, f.sum2, f.mean2, f.rstd2, f.ln2, f.d_sum2, f.ln_ws, f.d_sum2_drop, f.p_f, f.seed_f));
     const void* dyd = f.p_f > 0.f ? f.d_sum2_drop : f.d_sum2;
     // sum2 = dropout(h W2^T + b2) + a1;  h = gelu(pre): d_pre = (dyd W2) * gelu'(pre)
     VB_TRY(dgrad<B16>(st, f.M, f.f2, dyd, f.d_pre, nullptr, f.dact));
-    VB_TRY(wgrad_side<B16>(st, side, f.M, f.f2, dyd, f.h));
+    wq.push(f.M, f.f2, dyd, f.h);
     // d_a1 = d_pre W1 + d_sum2 (skip connection)
     VB_TRY(dgrad<B16>(st, f.M, f.f1, f.d_pre, f.d_a1, f.d_sum2, nullptr));
-    VB_TRY(wgrad_side<B16>(st, side, f.M, f.f1, f.d_pre, f.a1));
+    wq.push(f.M, f.f1, f.d_pre, f.a1);
     // a1 = LN(sum1)
     VB_TRY(ln_bwd<B16>(st, f.M, f.H, f.d_a1, f.sum1, f.mean1, f.rstd1, f.ln1, f.d_sum1, f.ln_ws, f.d_sum1_drop, f.p_o, f.seed_o));
     const void* dod = f.p_o > 0.f ? f.d_sum1_drop : f.d_sum1;
     // sum1 = dropout(ctx Wo^T + bo) + x
     VB_TRY(dgrad<B16>(st, f.M, f.o, dod, f.d_ctx, nullptr, nullptr));
-    return wgrad_side<B16>(st, side, f.M, f.o, dod, f.ctx);
+    wq.push(f.M, f.o, dod, f.ctx);
+    return 0;
 }
 
 template <bool B16>
-int attn_block_bwd(void* st, void* side, const vb_attn_block& b) {
+int attn_block_bwd(void* st, WgradQueue& wq, const vb_attn_block& b) {
     const long Hb = (long)b.heads * b.head_dim, M1 = (long)b.batch * b.n1;
     if (b.n2 == 0) {
         VB_TRY(attn_bwd<B16>(st, self_call(b, B16), b.d_ctx1, b.dqkv1, col<B16>(b.dqkv1, Hb), col<B16>(b.dqkv1, 2 * Hb), 3 * Hb,
@@ -325,11 +343,11 @@ int attn_block_bwd(void* st, void* side, const vb_attn_block& b) {
                              3 * Hb, b.dvec));
     }
     if (b.dx1 != nullptr) VB_TRY(dgrad<B16>(st, M1, b.qkv1, b.dqkv1, b.dx1, b.dres1, nullptr));
-    VB_TRY(wgrad_side<B16>(st, side, M1, b.qkv1, b.dqkv1, b.x1));
+    wq.push(M1, b.qkv1, b.dqkv1, b.x1);
     if (b.n2 != 0) {
         const long M2 = (long)b.batch * b.n2;
         if (b.dx2 != nullptr) VB_TRY(dgrad<B16>(st, M2, b.qkv2, b.dqkv2, b.dx2, b.dres2, nullptr));
-        VB_TRY(wgrad_side<B16>(st, side, M2, b.qkv2, b.dqkv2, b.x2));
+        wq.push(M2, b.qkv2, b.dqkv2, b.x2);
     }
     return 0;
 }
@@ -392,9 +410,15 @@ int layer_fwd(void* st, const vb_layer_args* a) {
 
 template <bool B16>
 int layer_bwd(void* st, const vb_layer_args* a) {
-    VB_TRY(ffn_block_bwd<B16>(st, a->wgrad_stream, a->s1));
-    VB_TRY(ffn_block_bwd<B16>(st, a->wgrad_stream, a->s2));
-    return a->attn.batch != 0 ? attn_block_bwd<B16>(st, a->wgrad_stream, a->attn) : 0;
+    // VB_WGRAD_FORK=each: the round-6 first form, one fork per weight gradient right behind its input gradient (A/B only)
+    static const bool each = [] { const char* e = getenv("VB_WGRAD_FORK"); return e != nullptr && e[0] == 'e'; }();
+    WgradQueue wq;
+    VB_TRY(ffn_block_bwd<B16>(st, wq, a->s1));
+    if (each) { VB_TRY(wgrad_flush<B16>(st, a->wgrad_stream, wq)); wq.n = 0; }
+    VB_TRY(ffn_block_bwd<B16>(st, wq, a->s2));
+    if (each) { VB_TRY(wgrad_flush<B16>(st, a->wgrad_stream, wq)); wq.n = 0; }
+    if (a->attn.batch != 0) VB_TRY(attn_block_bwd<B16>(st, wq, a->attn));
+    return wgrad_flush<B16>(st, a->wgrad_stream, wq);
 }
 
 }  // namespace
